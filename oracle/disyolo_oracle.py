@@ -1,0 +1,746 @@
+"""CPU oracle for the DIS-YOLO hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT.
+
+This file is a function-by-function CPU restatement (torch-CPU, f32 or f64) of
+the reference's TensorFlow-1.x graph ``yolo/yolo3_net_pos.py`` and of the
+optimizer line in ``train_yolo3_mask.py``.  Every function cites the reference
+lines it follows (paths relative to the reference checkout).
+
+PARITY UNPINNED: TensorFlow 1.x is not installable in the build container and
+the reference ships no tests, golden vectors, weights or checkpoints (SURVEY.md
+F1-F4), so this oracle could not be checked against outputs of the reference
+itself.  TF-op semantics it relies on are listed in SURVEY.md Appendix B and are
+marked [TF-sem] below.  What *is* pinned: hand-derived known answers in
+``tests/test_oracle_kat.py`` and the ``voc_eval`` fixtures generated from the
+importable reference module (``oracle/voc_eval_port.py``).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module.  The product (``dis-yolo_amd/``) never does.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# ---------------------------------------------------------------------------
+# constants restated from yolo/config.py:21-72 (checked against the golden
+# config.json generated from the reference module, tests/test_config.py)
+# ---------------------------------------------------------------------------
+CLASSES = ["crack", "spall", "rebar"]
+ANCHORS = np.array([[31, 23], [62, 58], [143, 91], [213, 186], [61, 337], [194, 432],
+                    [474, 248], [551, 93], [478, 454]], dtype=np.float32)
+ALPHA = 0.1
+K_MAP = 3
+OBJECT_SCALE, NOOBJECT_SCALE, CLASS_SCALE, COORD_SCALE, MASK_SCALE = 2.0, 1.0, 1.0, 1.0, 5.0
+IGNORE_THRESH = 0.5
+OBJ_THRESHOLD = 0.25
+IOU_THRESHOLD = 0.3
+MAX_BOX_PER_IMAGE = 20
+MAX_DETECTION = 30
+BN_DECAY, BN_EPS = 0.997, 1e-5          # yolo/yolo3_net_pos.py:74-75
+L2_WEIGHT = 1e-4                         # yolo/yolo3_net_pos.py:38
+NUM_ANCHOR = 3
+
+
+# ---------------------------------------------------------------------------
+# topology: (index, cin, cout, ksize, stride, kind) restated from
+# yolo/yolo3_net_pos.py:159-412.  kind: 'bn' = conv_bn, 'res' = res_conv_bn,
+# 'lin' = conv with bias and no activation.
+# ---------------------------------------------------------------------------
+def layer_specs() -> Dict[int, Tuple[int, int, int, int, str]]:
+    s: Dict[int, Tuple[int, int, int, int, str]] = {}
+    s[1] = (3, 32, 3, 1, "bn")                      # :159
+    s[2] = (32, 64, 3, 2, "bn")                     # :165
+    s[3] = (64, 32, 1, 1, "bn")                     # :170
+    s[4] = (32, 64, 3, 1, "res")                    # :174
+    s[5] = (64, 128, 3, 2, "bn")                    # :180
+    for i in (6, 8):                                # :185,:194
+        s[i] = (128, 64, 1, 1, "bn")
+        s[i + 1] = (64, 128, 3, 1, "res")           # :189,:198
+    s[10] = (128, 256, 3, 2, "bn")                  # :204
+    for i in range(8):                              # :208-218
+        s[2 * i + 11] = (256, 128, 1, 1, "bn")
+        s[2 * i + 12] = (128, 256, 3, 1, "res")
+    s[27] = (256, 512, 3, 2, "bn")                  # :222
+    for i in range(8):                              # :226-236
+        s[2 * i + 28] = (512, 256, 1, 1, "bn")
+        s[2 * i + 29] = (256, 512, 3, 1, "res")
+    s[44] = (512, 1024, 3, 2, "bn")                 # :240
+    for i in range(4):                              # :244-254
+        s[2 * i + 45] = (1024, 512, 1, 1, "bn")
+        s[2 * i + 46] = (512, 1024, 3, 1, "res")
+    for i in (53, 55, 57):                          # :258-272
+        s[i] = (1024, 512, 1, 1, "bn")
+    for i in (54, 56, 58):                          # :261-276
+        s[i] = (512, 1024, 3, 1, "bn")
+    s[59] = (1024, 24, 1, 1, "lin")                 # :277
+    s[60] = (512, 256, 1, 1, "bn")                  # :285
+    s[61] = (768, 256, 1, 1, "bn")                  # :293
+    for i in (62, 64, 66):                          # :296-311
+        s[i] = (256, 512, 3, 1, "bn")
+    for i in (63, 65):
+        s[i] = (512, 256, 1, 1, "bn")
+    s[67] = (512, 24, 1, 1, "lin")                  # :312
+    s[68] = (256, 128, 1, 1, "bn")                  # :320
+    s[69] = (384, 128, 1, 1, "bn")                  # :328
+    for i in (70, 72, 74):                          # :331-346
+        s[i] = (128, 256, 3, 1, "bn")
+    for i in (71, 73):
+        s[i] = (256, 128, 1, 1, "bn")
+    s[75] = (256, 24, 1, 1, "lin")                  # :347
+    s[76] = (128, 64, 1, 1, "bn")                   # :381
+    s[77] = (192, 64, 1, 1, "bn")                   # :389
+    s[78] = (64, 128, 3, 1, "bn")                   # :392
+    s[79] = (128, 32, 1, 1, "bn")                   # :396
+    s[80] = (96, 32, 1, 1, "bn")                    # :404
+    s[81] = (32, 64, 3, 1, "bn")                    # :407
+    s[82] = (64, 9, 1, 1, "lin")                    # :410
+    return s
+
+
+def default_lock(stage: int = 1) -> Dict[int, bool]:
+    """Stage 1 (shipped source): conv1-52 lock=True, 53-82 lock=False.
+    Stage 2: everything unlocked (yolo/yolo3_net_pos.py:155-156, README.md:19)."""
+    return {i: (stage == 1 and i <= 52) for i in range(1, 83)}
+
+
+def _name(i: int, leaf: str) -> str:
+    # variable names: train_yolo3_mask.py:86-103
+    return "yolo/convolutional%d/%s" % (i, leaf)
+
+
+def init_params(seed: int = 0, lock: Optional[Dict[int, bool]] = None,
+                dtype=torch.float32, num_class: int = 3, k: int = K_MAP,
+                xavier_locked: bool = False) -> Dict[str, torch.Tensor]:
+    """Random-init variables with the reference's initialisers.
+
+    Unlocked conv: xavier-uniform (yolo/yolo3_net_pos.py:118-119,138-139); locked
+    conv: truncated_normal(0, 0.001) (:112,:135); gamma=1, beta=0, moving_mean=0,
+    moving_variance=1 (:77-86); biases 0 (:115,:122).  ``xavier_locked`` draws the
+    locked layers from xavier-uniform too: a stand-in for the pretrained backbone the
+    reference restores over its 0.001-sigma placeholder init (train_yolo3_mask.py:75-107),
+    without which 52 locked layers underflow to zero.
+    """
+    lock = lock if lock is not None else default_lock(1)
+    g = torch.Generator().manual_seed(seed)
+    p: Dict[str, torch.Tensor] = {}
+    for i, (cin, cout, ks, _, kind) in layer_specs().items():
+        if kind == "lin":
+            cout = (num_class + 5) * NUM_ANCHOR if i != 82 else k * k
+        if lock[i] and not xavier_locked:
+            w = torch.empty(ks, ks, cin, cout, dtype=torch.float64)
+            torch.nn.init.trunc_normal_(w, 0.0, 0.001, -0.002, 0.002, generator=g)
+        else:
+            fan_in, fan_out = ks * ks * cin, ks * ks * cout
+            lim = math.sqrt(6.0 / (fan_in + fan_out))
+            w = (torch.rand(ks, ks, cin, cout, dtype=torch.float64, generator=g) * 2 - 1) * lim
+        p[_name(i, "weights")] = w.to(dtype)
+        if kind == "lin":
+            p[_name(i, "biases")] = torch.zeros(cout, dtype=dtype)
+        else:
+            p[_name(i, "BatchNorm/gamma")] = torch.ones(cout, dtype=dtype)
+            p[_name(i, "BatchNorm/beta")] = torch.zeros(cout, dtype=dtype)
+            p[_name(i, "BatchNorm/moving_mean")] = torch.zeros(cout, dtype=dtype)
+            p[_name(i, "BatchNorm/moving_variance")] = torch.ones(cout, dtype=dtype)
+    return p
+
+
+def trainable_names(lock: Dict[int, bool]) -> List[str]:
+    """tf.trainable_variables() restated: unlocked weights, gamma, beta, biases
+    (yolo/yolo3_net_pos.py:77-86,111-123,134-140)."""
+    out = []
+    for i, (_, _, _, _, kind) in layer_specs().items():
+        if lock[i]:
+            continue
+        out.append(_name(i, "weights"))
+        if kind == "lin":
+            out.append(_name(i, "biases"))
+        else:
+            out.append(_name(i, "BatchNorm/gamma"))
+            out.append(_name(i, "BatchNorm/beta"))
+    return out
+
+
+def regularized_names(lock: Dict[int, bool]) -> List[str]:
+    """Variables carrying l2_regularizer(1e-4): unlocked conv weights and the
+    biases of 59/67/75/82; never gamma/beta (yolo/yolo3_net_pos.py:38,120,123,140)."""
+    return [n for n in trainable_names(lock) if n.endswith("weights") or n.endswith("biases")]
+
+
+# ---------------------------------------------------------------------------
+# primitives  (yolo/yolo3_net_pos.py:68-151)
+# ---------------------------------------------------------------------------
+def leaky_relu(x: torch.Tensor, alpha: float = ALPHA) -> torch.Tensor:
+    """yolo/yolo3_net_pos.py:68-69  tf.maximum(alpha*x, x)."""
+    return torch.maximum(alpha * x, x)
+
+
+def same_pads(size: int, k: int, s: int) -> Tuple[int, int, int]:
+    """[TF-sem] padding='SAME': out=ceil(size/s); total=max((out-1)*s+k-size,0);
+    before=total//2, after=total-before (asymmetric for k=3,s=2, even size)."""
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    return out, total // 2, total - total // 2
+
+
+def conv2d_same(x: torch.Tensor, w_hwio: torch.Tensor, stride: int) -> torch.Tensor:
+    """tf.nn.conv2d(NHWC, HWIO, strides=[1,s,s,1], padding='SAME')
+    (yolo/yolo3_net_pos.py:125,142)."""
+    k = w_hwio.shape[0]
+    _, pt, pb = same_pads(x.shape[1], k, stride)
+    _, pl, pr = same_pads(x.shape[2], k, stride)
+    xn = x.permute(0, 3, 1, 2)
+    xn = F.pad(xn, (pl, pr, pt, pb))
+    y = F.conv2d(xn, w_hwio.permute(3, 2, 0, 1), stride=stride)
+    return y.permute(0, 2, 3, 1)
+
+
+def batch_norm(x: torch.Tensor, params: Dict[str, torch.Tensor], i: int, lock: bool,
+               is_training: bool, updates: Optional[Dict[str, torch.Tensor]]) -> torch.Tensor:
+    """yolo/yolo3_net_pos.py:71-107.
+
+    lock: moving stats always (:76-81).  Otherwise training: batch moments over
+    N,H,W with *population* variance (tf.nn.moments, :90 [TF-sem]); moving <-
+    decay*moving + (1-decay)*batch (:93-96); normalise with batch stats (:98).
+    Eval: moving stats (:101).  eps = 1e-5.
+    """
+    gamma = params[_name(i, "BatchNorm/gamma")]
+    beta = params[_name(i, "BatchNorm/beta")]
+    mm = params[_name(i, "BatchNorm/moving_mean")]
+    mv = params[_name(i, "BatchNorm/moving_variance")]
+    if lock or not is_training:
+        mean, var = mm, mv
+    else:
+        mean = x.mean(dim=(0, 1, 2))
+        var = ((x - mean) ** 2).mean(dim=(0, 1, 2))
+        if updates is not None:
+            updates[_name(i, "BatchNorm/moving_mean")] = (mm * BN_DECAY + mean.detach() * (1 - BN_DECAY))
+            updates[_name(i, "BatchNorm/moving_variance")] = (mv * BN_DECAY + var.detach() * (1 - BN_DECAY))
+    # tf.nn.batch_normalization: (x-mean)*rsqrt(var+eps)*gamma + beta
+    return (x - mean) * torch.rsqrt(var + BN_EPS) * gamma + beta
+
+
+def conv_bn(x, params, i, stride, lock, is_training, updates, alpha=ALPHA):
+    """yolo/yolo3_net_pos.py:132-146."""
+    y = conv2d_same(x, params[_name(i, "weights")], stride)
+    y = batch_norm(y, params, i, lock, is_training, updates)
+    return leaky_relu(y, alpha)
+
+
+def conv_lin(x, params, i):
+    """yolo/yolo3_net_pos.py:109-130 with is_bias=True, is_act=False (all 4 call sites)."""
+    return conv2d_same(x, params[_name(i, "weights")], 1) + params[_name(i, "biases")]
+
+
+def upsample2(x: torch.Tensor) -> torch.Tensor:
+    """tf.image.resize_nearest_neighbor to 2x (yolo/yolo3_net_pos.py:290,325,386,401):
+    out[y,x] = in[y>>1, x>>1] [TF-sem]."""
+    return x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+
+
+def build_network(params: Dict[str, torch.Tensor], images: torch.Tensor, is_training: bool,
+                  lock: Dict[int, bool], updates: Optional[Dict[str, torch.Tensor]] = None,
+                  taps: Optional[Dict[str, torch.Tensor]] = None):
+    """yolo/yolo3_net_pos.py:153-463 (the active m=1/2 mask subnet, :380-412).
+
+    Returns (yolos=[yolov3_3, yolov3_2, yolov3_1] each [B,g,g,3,5+C], mask_pos
+    [B,S/2,S/2,k*k]).  ``taps`` (optional) collects intermediate activations by
+    name ('act{i}') for per-layer parity tests.
+    """
+    sp = layer_specs()
+
+    def cb(x, i):
+        y = conv_bn(x, params, i, sp[i][3], lock[i], is_training, updates)
+        return y
+
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t
+        return t
+
+    net = tap("act1", cb(images, 1))                                     # :159
+    net = tap("act2", cb(net, 2))                                        # :165
+    skips = {}
+    i = 3
+    for nblocks, skipname, down in ((1, "skip2", 5), (2, "skip3", 10), (8, "skip4", 27),
+                                    (8, "skip5", 44), (4, None, None)):
+        for _ in range(nblocks):
+            shortcut = net
+            net = tap("act%d" % i, cb(net, i))                           # 1x1
+            net = tap("act%d" % (i + 1), cb(net, i + 1) + shortcut)      # res add after act (:148-151)
+            i += 2
+        if skipname:
+            skips[skipname] = net
+            net = tap("act%d" % down, cb(net, down))
+            i = down + 1
+    # head 1 (:258-281)
+    for i in (53, 54, 55, 56, 57):
+        net = tap("act%d" % i, cb(net, i))
+    y1 = tap("act58", cb(net, 58))
+    y1 = tap("act59", conv_lin(y1, params, 59))
+    B = images.shape[0]
+    yolov3_1 = y1.reshape(B, y1.shape[1], y1.shape[2], NUM_ANCHOR, -1)
+    # head 2 (:285-316)
+    net = tap("act60", cb(net, 60))
+    net = torch.cat([skips["skip5"], upsample2(net)], dim=-1)            # :290-291 [skip, up]
+    for i in (61, 62, 63, 64, 65):
+        net = tap("act%d" % i, cb(net, i))
+    y2 = tap("act66", cb(net, 66))
+    y2 = tap("act67", conv_lin(y2, params, 67))
+    yolov3_2 = y2.reshape(B, y2.shape[1], y2.shape[2], NUM_ANCHOR, -1)
+    # head 3 (:320-351)
+    net = tap("act68", cb(net, 68))
+    net = torch.cat([skips["skip4"], upsample2(net)], dim=-1)            # :325-326
+    for i in (69, 70, 71, 72, 73):
+        net = tap("act%d" % i, cb(net, i))
+    y3 = tap("act74", cb(net, 74))
+    y3 = tap("act75", conv_lin(y3, params, 75))
+    yolov3_3 = y3.reshape(B, y3.shape[1], y3.shape[2], NUM_ANCHOR, -1)
+    # mask subnet m=1/2 (:381-412), branches from conv73's output
+    net = tap("act76", cb(net, 76))
+    net = torch.cat([skips["skip3"], upsample2(net)], dim=-1)            # :386-387
+    net = tap("act77", cb(net, 77))
+    net = tap("act78", cb(net, 78))
+    net = tap("act79", cb(net, 79))
+    net = torch.cat([skips["skip2"], upsample2(net)], dim=-1)            # :401-402
+    net = tap("act80", cb(net, 80))
+    net = tap("act81", cb(net, 81))
+    mask_pos = tap("act82", conv_lin(net, params, 82))                   # :410
+    return [yolov3_3, yolov3_2, yolov3_1], mask_pos
+
+
+# ---------------------------------------------------------------------------
+# decode  (yolo/yolo3_net_pos.py:465-514)
+# ---------------------------------------------------------------------------
+def cell_offset(gh: int, gw: int, dtype) -> torch.Tensor:
+    """self.offset[:, :gh, :gw] (yolo/yolo3_net_pos.py:23-26): [...,0]=x index, [...,1]=y index."""
+    cx = torch.arange(gw, dtype=dtype).view(1, 1, gw, 1, 1).expand(1, gh, gw, NUM_ANCHOR, 1)
+    cy = torch.arange(gh, dtype=dtype).view(1, gh, 1, 1, 1).expand(1, gh, gw, NUM_ANCHOR, 1)
+    return torch.cat([cx, cy], dim=-1)
+
+
+def interpret_output(predicts: Sequence[torch.Tensor], anchors=ANCHORS):
+    """yolo/yolo3_net_pos.py:465-514.  predicts = [72-grid, 36-grid, 18-grid]."""
+    dtype = predicts[0].dtype
+    net_h = predicts[2].shape[1] * 32
+    net_w = predicts[2].shape[2] * 32
+    net_factor = torch.tensor([net_w, net_h], dtype=dtype).view(1, 1, 1, 1, 2)
+    anchors_pwhs, conf_logits, class_logits, pred_coords, pred_norm_coords = [], [], [], [], []
+    for i in (0, 1, 2):
+        preds = predicts[i]
+        gh, gw = preds.shape[1], preds.shape[2]
+        grid_factor = torch.tensor([gw, gh], dtype=dtype).view(1, 1, 1, 1, 2)
+        pred_conf = preds[..., 4:5]
+        pred_class = preds[..., 5:]
+        pred_cxy = torch.sigmoid(preds[..., :2])
+        pred_twh = preds[..., 2:4]
+        box_xy = cell_offset(gh, gw, dtype) + pred_cxy
+        a = torch.tensor(np.asarray(anchors, dtype=np.float64)[3 * i:3 * i + 3], dtype=dtype)  # [3,2] (w,h)
+        anchors_pwh = a.view(1, 1, 1, NUM_ANCHOR, 2).expand(preds.shape[0], gh, gw, NUM_ANCHOR, 2)
+        box_wh = torch.exp(pred_twh) * anchors_pwh
+        pred_norm_coord = torch.cat([box_xy / grid_factor, box_wh / net_factor], dim=-1)
+        anchors_pwhs.append(anchors_pwh)
+        conf_logits.append(pred_conf)
+        class_logits.append(pred_class)
+        pred_coords.append(torch.cat([pred_cxy, pred_twh], dim=-1))
+        pred_norm_coords.append(pred_norm_coord)
+    return [[net_h, net_w], anchors_pwhs, conf_logits, class_logits, pred_coords, pred_norm_coords]
+
+
+# ---------------------------------------------------------------------------
+# detection filter  (yolo/yolo3_net_pos.py:517-628, 940-952)
+# ---------------------------------------------------------------------------
+def clip_boxes(boxes: np.ndarray, window: np.ndarray) -> np.ndarray:
+    """clip_boxes_graph, yolo/yolo3_net_pos.py:940-952: max(min(v, hi), lo)."""
+    wy1, wx1, wy2, wx2 = window
+    out = boxes.copy()
+    out[:, 0] = np.maximum(np.minimum(boxes[:, 0], wy2), wy1)
+    out[:, 1] = np.maximum(np.minimum(boxes[:, 1], wx2), wx1)
+    out[:, 2] = np.maximum(np.minimum(boxes[:, 2], wy2), wy1)
+    out[:, 3] = np.maximum(np.minimum(boxes[:, 3], wx2), wx1)
+    return out
+
+
+def _tf_iou(a: np.ndarray, b: np.ndarray) -> float:
+    """[TF-sem] IoU as tf.image.non_max_suppression computes it (f32): corner order
+    normalised with min/max; zero-area box => IoU 0."""
+    f = np.float32
+    ya1, xa1, ya2, xa2 = f(min(a[0], a[2])), f(min(a[1], a[3])), f(max(a[0], a[2])), f(max(a[1], a[3]))
+    yb1, xb1, yb2, xb2 = f(min(b[0], b[2])), f(min(b[1], b[3])), f(max(b[0], b[2])), f(max(b[1], b[3]))
+    area_a = f(f(ya2 - ya1) * f(xa2 - xa1))
+    area_b = f(f(yb2 - yb1) * f(xb2 - xb1))
+    if area_a <= 0 or area_b <= 0:
+        return 0.0
+    iy1, ix1, iy2, ix2 = max(ya1, yb1), max(xa1, xb1), min(ya2, yb2), min(xa2, xb2)
+    inter = f(max(f(iy2 - iy1), f(0)) * max(f(ix2 - ix1), f(0)))
+    return float(f(inter / f(f(area_a + area_b) - inter)))
+
+
+def non_max_suppression(boxes: np.ndarray, scores: np.ndarray, max_out: int, iou_thresh: float) -> List[int]:
+    """[TF-sem] tf.image.non_max_suppression: visit candidates by descending score
+    (ties: lower index first -- not verifiable without TF); keep a box
+    unless its IoU with an already kept box is > iou_thresh; stop at max_out."""
+    order = sorted(range(len(scores)), key=lambda j: (-float(scores[j]), j))
+    keep: List[int] = []
+    for j in order:
+        if len(keep) >= max_out:
+            break
+        if all(_tf_iou(boxes[j], boxes[q]) <= iou_thresh for q in keep):
+            keep.append(j)
+    return keep
+
+
+def filter_detections(conf_logit, class_logit, pred_norm_coord, batch_window, obj_thresh=OBJ_THRESHOLD,
+                      nms_thresh=IOU_THRESHOLD, max_detection=MAX_DETECTION) -> np.ndarray:
+    """yolo/yolo3_net_pos.py:517-628.  Returns float32 [B, max_detection, 6]
+    rows (y1,x1,y2,x2,classid,score), score-descending, zero padded.  All scoring
+    arithmetic is done in f32 like the reference graph."""
+    B = conf_logit[0].shape[0]
+    out = np.zeros((B, max_detection, 6), dtype=np.float32)
+    for i in range(B):
+        confs, clss, boxes = [], [], []
+        for j in (0, 1, 2):                                             # :527-538 order 72,36,18
+            confs.append(torch.sigmoid(conf_logit[j][i].float()).reshape(-1))
+            clss.append(torch.softmax(class_logit[j][i].float(), dim=-1).reshape(-1, class_logit[j].shape[-1]))
+            boxes.append(pred_norm_coord[j][i].float().reshape(-1, 4))
+        pred_conf = torch.cat(confs).numpy()
+        pred_class = torch.cat(clss).numpy()
+        box = torch.cat(boxes).numpy()
+        classid = np.argmax(pred_class, axis=-1).astype(np.int32)       # :545 (first max wins)
+        classmax = pred_class[np.arange(pred_class.shape[0]), classid]
+        score = (pred_conf * classmax).astype(np.float32)               # :548
+        xc, yc, w, h = box[:, 0], box[:, 1], box[:, 2], box[:, 3]
+        half = np.float32(2.0)
+        yxyx = np.stack([yc - h / half, xc - w / half, yc + h / half, xc + w / half], axis=-1).astype(np.float32)
+        yxyx = clip_boxes(yxyx, np.asarray(batch_window[i], dtype=np.float32))      # :552-555
+        keep = np.where(score > np.float32(obj_thresh))[0]              # :558
+        nms_keep: List[int] = []
+        for c in np.unique(classid[keep]):                              # :565-589 per-class NMS
+            ixs = keep[classid[keep] == c]
+            ck = non_max_suppression(yxyx[ixs], score[ixs], max_detection, nms_thresh)
+            nms_keep.extend(int(ixs[q]) for q in ck)
+        keep = np.array(sorted(set(nms_keep)), dtype=np.int64)          # :590-592 set_intersection => ascending ids
+        num_keep = min(len(keep), max_detection)                        # :608-612 top_k, ties: lower index first
+        order = sorted(range(len(keep)), key=lambda q: (-float(score[keep[q]]), q))[:num_keep]
+        keep = keep[order] if len(keep) else keep
+        for r, idx in enumerate(keep):
+            out[i, r, :4] = yxyx[idx]
+            out[i, r, 4] = np.float32(classid[idx])
+            out[i, r, 5] = score[idx]
+    return out
+
+
+# ---------------------------------------------------------------------------
+# YOLO loss  (yolo/yolo3_net_pos.py:631-747)
+# ---------------------------------------------------------------------------
+def sigmoid_ce(labels: torch.Tensor, logits: torch.Tensor) -> torch.Tensor:
+    """[TF-sem] tf.nn.sigmoid_cross_entropy_with_logits: max(x,0) - x*z + log1p(exp(-|x|))."""
+    return torch.clamp(logits, min=0) - logits * labels + torch.log1p(torch.exp(-torch.abs(logits)))
+
+
+def loss_yolo(predicts, true_boxes: torch.Tensor, labels_value: Sequence[torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """yolo/yolo3_net_pos.py:631-747.  labels_value = [yolo3, yolo2, yolo1] (:55)."""
+    (net_h, net_w), anchors_pwhs, conf_logits, class_logits, pred_coords, pred_norm_coords = predicts
+    dtype = conf_logits[0].dtype
+    acc = {k: torch.zeros((), dtype=dtype) for k in ("obj", "noobj", "xy", "wh", "conf", "class", "coord")}
+    for i in range(3):
+        pnc = pred_norm_coords[i]
+        pred_xy = pnc[..., :2].unsqueeze(4)
+        pred_wh = pnc[..., 2:4].unsqueeze(4)
+        pred_mins, pred_maxes = pred_xy - pred_wh / 2.0, pred_xy + pred_wh / 2.0
+        true_xy, true_wh = true_boxes[..., 0:2], true_boxes[..., 2:4]
+        true_mins, true_maxes = true_xy - true_wh / 2.0, true_xy + true_wh / 2.0
+        iwh = torch.clamp(torch.minimum(pred_maxes, true_maxes) - torch.maximum(pred_mins, true_mins), min=0.0)
+        inter = iwh[..., 0] * iwh[..., 1]
+        true_areas = true_wh[..., 0] * true_wh[..., 1]
+        pred_areas = pred_wh[..., 0] * pred_wh[..., 1]
+        union = torch.clamp(pred_areas + true_areas - inter, min=1e-10)            # :676
+        iou = torch.clamp(inter / union, 0.0, 1.0)
+        best = iou.max(dim=4).values
+        ignore = (best < IGNORE_THRESH).to(dtype).unsqueeze(4)                     # :680
+        obj_val = labels_value[i]
+        pred_conf = conf_logits[i]
+        obj_mask = obj_val[..., 4:5]
+        noobj_mask = 1.0 - obj_mask
+        ce = sigmoid_ce(obj_mask, pred_conf)
+        object_loss = (obj_mask * ce * OBJECT_SCALE).sum(dim=(1, 2, 3, 4)).mean()                  # :691-692
+        noobject_loss = (ignore * noobj_mask * ce * NOOBJECT_SCALE).sum(dim=(1, 2, 3, 4)).mean()   # :693-694
+        true_cls = obj_val[..., 5:].argmax(dim=-1)                                                 # :699
+        logp = torch.log_softmax(class_logits[i], dim=-1)
+        sce = -logp.gather(-1, true_cls.unsqueeze(-1))                                             # :701
+        class_loss = (obj_mask * sce * CLASS_SCALE).sum(dim=(1, 2, 3, 4)).mean()
+        gh, gw = pred_conf.shape[1], pred_conf.shape[2]
+        grid_factor = torch.tensor([gw, gh], dtype=dtype).view(1, 1, 1, 1, 2)
+        net_factor = torch.tensor([net_w, net_h], dtype=dtype).view(1, 1, 1, 1, 2)
+        tb = obj_val[..., 0:4]
+        true_cxy = tb[..., 0:2] * grid_factor - cell_offset(gh, gw, dtype)                         # :714
+        true_twh = torch.clamp(torch.log(tb[..., 2:4] * net_factor / anchors_pwhs[i]), -1e2, 1e2)  # :717-718
+        wh_scale = (2.0 - tb[..., 2] * tb[..., 3]).unsqueeze(4)                                    # :721-722
+        cxy_delta = obj_mask * (pred_coords[i][..., :2] - true_cxy)
+        twh_delta = obj_mask * (pred_coords[i][..., 2:4] - true_twh)
+        xy_loss = (cxy_delta ** 2 * wh_scale ** 2 * COORD_SCALE).sum(dim=(1, 2, 3, 4)).mean()      # :725
+        wh_loss = (twh_delta ** 2 * wh_scale ** 2 * COORD_SCALE).sum(dim=(1, 2, 3, 4)).mean()      # :726
+        acc["obj"] = acc["obj"] + object_loss
+        acc["noobj"] = acc["noobj"] + noobject_loss
+        acc["xy"] = acc["xy"] + xy_loss
+        acc["wh"] = acc["wh"] + wh_loss
+        acc["conf"] = acc["conf"] + object_loss + noobject_loss
+        acc["class"] = acc["class"] + class_loss
+        acc["coord"] = acc["coord"] + xy_loss + wh_loss
+    return acc
+
+
+# ---------------------------------------------------------------------------
+# position-sensitive assembly + mask loss  (yolo/yolo3_net_pos.py:750-860, 954-975)
+# ---------------------------------------------------------------------------
+def overlaps(boxes1: np.ndarray, boxes2: np.ndarray) -> np.ndarray:
+    """overlaps_graph, yolo/yolo3_net_pos.py:954-975 (f32, no epsilon on the union)."""
+    b1 = boxes1.astype(np.float32)[:, None, :]
+    b2 = boxes2.astype(np.float32)[None, :, :]
+    y1 = np.maximum(b1[..., 0], b2[..., 0]); x1 = np.maximum(b1[..., 1], b2[..., 1])
+    y2 = np.minimum(b1[..., 2], b2[..., 2]); x2 = np.minimum(b1[..., 3], b2[..., 3])
+    inter = np.maximum(x2 - x1, 0) * np.maximum(y2 - y1, 0)
+    a1 = (b1[..., 2] - b1[..., 0]) * (b1[..., 3] - b1[..., 1])
+    a2 = (b2[..., 2] - b2[..., 0]) * (b2[..., 3] - b2[..., 1])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (inter / (a1 + a2 - inter)).astype(np.float32)
+
+
+def kmask_edges(lo: float, hi: float, k: int = K_MAP) -> List[int]:
+    """Bin edges along one axis, yolo/yolo3_net_pos.py:804-813: [int(lo),
+    round(lo + j*(hi-lo)/k) for j=1..k-1, int(hi)], f32 arithmetic, tf.round =
+    half-to-even, tf.cast(int32) = truncation [TF-sem]."""
+    f = np.float32
+    lo, hi = f(lo), f(hi)
+    sub = f(f(hi - lo) / f(k))
+    edges = [int(lo)]
+    for j in range(1, k):
+        edges.append(int(np.round(f(lo + f(f(j) * sub)))))
+    edges.append(int(hi))
+    return edges
+
+
+def channel_index_map(box: Sequence[float], size: int, k: int = K_MAP) -> np.ndarray:
+    """assemble_kmask_from_box, yolo/yolo3_net_pos.py:799-839, as an index map:
+    int32 [size,size], value = by*k+bx inside bin (by,bx), -1 elsewhere."""
+    gy = kmask_edges(box[0], box[2], k)
+    gx = kmask_edges(box[1], box[3], k)
+    m = -np.ones((size, size), dtype=np.int32)
+    for by in range(k):
+        for bx in range(k):
+            y1, y2, x1, x2 = gy[by], gy[by + 1], gx[bx], gx[bx + 1]
+            if y2 > y1 and x2 > x1:
+                m[max(y1, 0):min(y2, size), max(x1, 0):min(x2, size)] = by * k + bx
+    return m
+
+
+def assemble_logits(score_maps: torch.Tensor, box: Sequence[float], k: int = K_MAP):
+    """reduce_sum(pred_masks * channel_masks, -1) for one box
+    (yolo/yolo3_net_pos.py:843-848): returns (logits [S,S] -- 0 outside the box,
+    mask_object [S,S] in {0,1})."""
+    size = score_maps.shape[0]
+    idx = torch.from_numpy(channel_index_map(box, size, k)).long()
+    inside = idx >= 0
+    logits = torch.gather(score_maps, 2, idx.clamp(min=0).unsqueeze(-1)).squeeze(-1)
+    logits = torch.where(inside, logits, torch.zeros_like(logits))
+    return logits, inside.to(score_maps.dtype)
+
+
+def select_mask_rois(detections_i: np.ndarray, true_boxes_i: np.ndarray,
+                     perm_det: Optional[Sequence[int]] = None, perm_gt: Optional[Sequence[int]] = None):
+    """yolo/yolo3_net_pos.py:757-796.  Returns (positive_rois [P,4] normalised yxyx,
+    gt_assignment [P] index into the *trimmed* GT list, gt_index_map: trimmed->row).
+
+    tf.random_shuffle (:781-782) is replaced by the injected permutations
+    (identity when None) -- the reference is non-deterministic here.
+    """
+    prop = detections_i[:, :4].astype(np.float32)
+    prop = prop[np.abs(prop).sum(axis=1) != 0]                                         # :759-760
+    gt = true_boxes_i[:, :4].astype(np.float32)
+    gt_rows = np.where(np.abs(gt).sum(axis=1) != 0)[0]                                 # :766-769
+    gt = gt[gt_rows]
+    xc, yc, w, h = gt[:, 0], gt[:, 1], gt[:, 2], gt[:, 3]
+    two = np.float32(2.0)
+    gt_yxyx = np.stack([yc - h / two, xc - w / two, yc + h / two, xc + w / two], axis=-1).astype(np.float32)  # :778-779
+    pd = list(range(len(prop))) if perm_det is None else [q for q in perm_det if q < len(prop)]
+    pg = list(range(len(gt_yxyx))) if perm_gt is None else [q for q in perm_gt if q < len(gt_yxyx)]
+    rois = np.concatenate([prop[pd][:7], gt_yxyx[pg][:3]], axis=0)                     # :783
+    if len(rois) == 0 or len(gt_yxyx) == 0:
+        return np.zeros((0, 4), np.float32), np.zeros((0,), np.int64), gt_rows
+    ov = overlaps(rois, gt_yxyx)                                                       # :784
+    iou_max = ov.max(axis=1)
+    pos = np.where(iou_max >= np.float32(0.5))[0]                                      # :787-789
+    return rois[pos], ov[pos].argmax(axis=1), gt_rows
+
+
+def loss_mask(detections: np.ndarray, mask_pos: torch.Tensor, true_boxes: np.ndarray, true_masks: np.ndarray,
+              perms: Optional[Sequence[Tuple[Sequence[int], Sequence[int]]]] = None) -> torch.Tensor:
+    """yolo/yolo3_net_pos.py:750-860.  detections [B,30,6] (constant wrt autograd, the
+    boxes pass through tf.round), mask_pos [B,S,S,k*k] torch, true_boxes
+    [B,1,1,1,20,5], true_masks bool [B,20,2S,2S]."""
+    B, size = mask_pos.shape[0], mask_pos.shape[1]
+    dtype = mask_pos.dtype
+    total = torch.zeros((), dtype=dtype)
+    for i in range(B):
+        pd, pg = perms[i] if perms is not None else (None, None)
+        pos_rois, assign, gt_rows = select_mask_rois(detections[i], true_boxes[i, 0, 0, 0], pd, pg)
+        if len(pos_rois) == 0:                                                         # :855
+            continue
+        # GT masks -> score-map size: legacy bilinear at exact 2x == [::2, ::2], then round (:771-775) [TF-sem]
+        step = true_masks.shape[2] // size
+        gt_small = true_masks[i][gt_rows][:, ::step, ::step].astype(np.float32)
+        rois_px = np.round(pos_rois * np.float32(size))                                # :842 half-to-even
+        per_roi = []
+        for r in range(len(rois_px)):
+            logits, mobj = assemble_logits(mask_pos[i], rois_px[r])
+            gtm = torch.from_numpy(gt_small[assign[r]]).to(dtype)
+            num = (mobj * sigmoid_ce(gtm, logits)).sum()                               # :850
+            per_roi.append(num / mobj.sum())                                           # :852 (0/0 -> nan)
+        total = total + MASK_SCALE * torch.stack(per_roi).mean()
+    return total / B                                                                   # :858
+
+
+def val_test(detections: np.ndarray, mask_pos: torch.Tensor):
+    """yolo/yolo3_net_pos.py:862-938.  Returns (det_box list of [n,6] f32, det_mask
+    list of [n,S,S] f32 or scalar 0.0).  Outside the box the value is sigmoid(0)=0.5."""
+    det_box, det_mask = [], []
+    B, size = mask_pos.shape[0], mask_pos.shape[1]
+    for i in range(B):
+        prop = detections[i].astype(np.float32)
+        pb = np.round(prop[:, :4] * np.float32(size))                                  # :876
+        keep = np.where(((pb[:, 2] - pb[:, 0]) > 0) & ((pb[:, 3] - pb[:, 1]) > 0))[0]  # :877-878
+        prop, pb = prop[keep], pb[keep]
+        if prop.size > 0:
+            masks = [torch.sigmoid(assemble_logits(mask_pos[i], pb[r])[0]) for r in range(len(pb))]
+            det_mask.append(torch.stack(masks).float().numpy())
+        else:
+            det_mask.append(np.float32(0.0))                                           # :933
+        det_box.append(prop)
+    return det_box, det_mask
+
+
+# ---------------------------------------------------------------------------
+# total loss + optimizer
+# ---------------------------------------------------------------------------
+def l2_regularization(params: Dict[str, torch.Tensor], lock: Dict[int, bool]) -> torch.Tensor:
+    """[TF-sem] tf.contrib.layers.l2_regularizer(1e-4)(w) = 1e-4 * sum(w^2)/2, added by
+    tf.losses.get_total_loss() (yolo/yolo3_net_pos.py:38,61)."""
+    tot = None
+    for n in regularized_names(lock):
+        t = L2_WEIGHT * 0.5 * (params[n] ** 2).sum()
+        tot = t if tot is None else tot + t
+    return tot
+
+
+def total_loss(params, batch, lock, is_training=True, perms=None, updates=None, obj_thresh=OBJ_THRESHOLD):
+    """YOLONet.__init__ wiring, yolo/yolo3_net_pos.py:47-61.  ``batch`` keys: images,
+    clip_window, true_boxes, true_masks, yolo1, yolo2, yolo3 (torch / numpy)."""
+    yolos, mask_pos = build_network(params, batch["images"], is_training, lock, updates)
+    pred = interpret_output(yolos)
+    with torch.no_grad():
+        det = filter_detections(pred[2], pred[3], pred[5], batch["clip_window"], obj_thresh)
+    ly = loss_yolo(pred, batch["true_boxes"], [batch["yolo3"], batch["yolo2"], batch["yolo1"]])
+    lm = loss_mask(det, mask_pos, batch["true_boxes"].detach().numpy(), batch["true_masks"], perms)
+    reg = l2_regularization(params, lock)
+    parts = dict(ly)
+    parts["mask"] = lm
+    parts["reg"] = reg
+    parts["total"] = ly["conf"] + ly["class"] + ly["coord"] + lm + reg
+    return parts, det, yolos, mask_pos
+
+
+def adam_tf_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, t: int,
+                 lr=1e-4, b1=0.9, b2=0.999, eps=1e-8):
+    """[TF-sem] tf.train.AdamOptimizer (train_yolo3_mask.py:55): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
+    m <- b1 m + (1-b1) g; v <- b2 v + (1-b2) g^2; p <- p - lr_t * m / (sqrt(v) + eps).  t starts at 1."""
+    lr_t = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    p = p - lr_t * m / (torch.sqrt(v) + eps)
+    return p, m, v
+
+
+# ---------------------------------------------------------------------------
+# synthetic batch incl. the target assignment of utils/train_data.py:149-178
+# ---------------------------------------------------------------------------
+def assign_targets(boxes_px: np.ndarray, cls: np.ndarray, S: int, anchors=ANCHORS, num_class=3):
+    """utils/train_data.py:149-178: best-IoU anchor of the 9 (centred boxes), cell =
+    int(xc*g/net), skip if occupied.  boxes_px rows (xc,yc,w,h) in pixels.
+    Returns yolo3 (S/8 grid), yolo2, yolo1 with pixel coords (caller divides by S, :258-261)."""
+    g1 = S // 32
+    yolos = [np.zeros((4 * g1, 4 * g1, 3, 5 + num_class), np.float32),
+             np.zeros((2 * g1, 2 * g1, 3, 5 + num_class), np.float32),
+             np.zeros((g1, g1, 3, 5 + num_class), np.float32)]
+    amax = np.asarray(anchors, np.float32) / 2.0
+    a_area = amax[:, 0] * amax[:, 1] * 4
+    for b, c in zip(boxes_px, cls):
+        half = np.asarray(b[2:4], np.float32) / 2.0
+        imax = np.minimum(half[None, :], amax)
+        inter = np.maximum(2 * imax, 0.0)
+        ia = inter[:, 0] * inter[:, 1]
+        iou = ia / (half[0] * half[1] * 4 + a_area - ia)
+        if iou.max() <= 0:
+            continue
+        idx = int(np.argmax(iou))
+        y = yolos[idx // 3]
+        xi = int(b[0] * y.shape[1] / S)
+        yi = int(b[1] * y.shape[0] / S)
+        if y[yi, xi, idx % 3, 4] == 1:
+            continue
+        y[yi, xi, idx % 3, 0:4] = b[:4]
+        y[yi, xi, idx % 3, 4] = 1
+        y[yi, xi, idx % 3, 5 + int(c)] = 1.0
+    return yolos
+
+
+def synthetic_batch(B: int, S: int, seed: int = 1234, dtype=torch.float32, num_class: int = 3):
+    """Seeded synthetic training batch: uniform images, 1..5 ellipse
+    instances per image with tight boxes, masks [B,20,S,S], targets via assign_targets."""
+    rng = np.random.RandomState(seed)
+    images = rng.rand(B, S, S, 3).astype(np.float32)
+    true_boxes = np.zeros((B, 1, 1, 1, MAX_BOX_PER_IMAGE, 5), np.float32)
+    true_masks = np.zeros((B, MAX_BOX_PER_IMAGE, S, S), bool)
+    y3 = np.zeros((B, S // 8, S // 8, 3, 5 + num_class), np.float32)
+    y2 = np.zeros((B, S // 16, S // 16, 3, 5 + num_class), np.float32)
+    y1 = np.zeros((B, S // 32, S // 32, 3, 5 + num_class), np.float32)
+    yy, xx = np.mgrid[0:S, 0:S]
+    for b in range(B):
+        n = rng.randint(1, 6)
+        bx, cl = [], []
+        for j in range(n):
+            w = rng.uniform(0.05, 0.6) * S
+            h = rng.uniform(0.05, 0.6) * S
+            cx = rng.uniform(w / 2, S - w / 2)
+            cy = rng.uniform(h / 2, S - h / 2)
+            m = ((xx - cx) / (w / 2)) ** 2 + ((yy - cy) / (h / 2)) ** 2 <= 1.0
+            if not m.any():
+                continue
+            ys, xs = np.where(m)
+            x1, x2, y1_, y2_ = xs.min(), xs.max(), ys.min(), ys.max()
+            true_masks[b, j] = m
+            c = rng.randint(0, num_class)
+            box = [(x1 + x2) / 2.0, (y1_ + y2_) / 2.0, float(x2 - x1), float(y2_ - y1_)]
+            if box[2] <= 0 or box[3] <= 0:
+                true_masks[b, j] = False
+                continue
+            true_boxes[b, 0, 0, 0, j, :4] = np.asarray(box, np.float32) / S
+            true_boxes[b, 0, 0, 0, j, 4] = c
+            bx.append(box)
+            cl.append(c)
+        t3, t2, t1 = assign_targets(np.asarray(bx, np.float32).reshape(-1, 4), np.asarray(cl), S, num_class=num_class)
+        for t in (t3, t2, t1):
+            t[..., 0:4] /= S
+        y3[b], y2[b], y1[b] = t3, t2, t1
+    window = np.tile(np.array([[0.0, 0.0, 1.0, 1.0]], np.float32), (B, 1))
+    return {
+        "images": torch.from_numpy(images).to(dtype),
+        "clip_window": window,
+        "true_boxes": torch.from_numpy(true_boxes).to(dtype),
+        "true_masks": true_masks,
+        "yolo1": torch.from_numpy(y1).to(dtype),
+        "yolo2": torch.from_numpy(y2).to(dtype),
+        "yolo3": torch.from_numpy(y3).to(dtype),
+    }
