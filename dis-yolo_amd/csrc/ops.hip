@@ -1,0 +1,202 @@
+// First-layer convolution, weight packing, Adam and the l2 term.
+#include <stdarg.h>
+#include "common.h"
+
+// ---- error reporting -------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void disyolo_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* disyolo_last_error(void) { return g_err; }
+extern "C" int disyolo_version(void) { return 100; }
+
+namespace {
+
+// ---- conv 1: Cin = 3, k = 3, s = 1, SAME (yolo/yolo3_net_pos.py:159) ---------------
+// Exact f32 FMA (27 taps) per output; 1 thread = 1 pixel x 8 output channels.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_first_kernel(const float* img, const float* w, const float* scale,
+                                                         const float* shift, bf16* y, int B, int H, int W,
+                                                         float alpha) {
+  __shared__ float sw[27 * COUT];
+  for (int i = threadIdx.x; i < 27 * COUT; i += 256) sw[i] = w[i];
+  __syncthreads();
+  constexpr int G = COUT / 8;
+  const int64_t total = (int64_t)B * H * W * G;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int cg = (int)(t % G);
+    int64_t m = t / G;
+    const int x = (int)(m % W);
+    const int64_t m2 = m / W;
+    const int yy = (int)(m2 % H);
+    const int b = (int)(m2 / H);
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = yy + kh - 1;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ix = x + kw - 1;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const float* px = img + ((size_t)(b * H + iy) * W + ix) * 3;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+          const float v = px[ci];
+          const float* wr = sw + ((kh * 3 + kw) * 3 + ci) * COUT + cg * 8;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[k] = fmaf(v, wr[k], acc[k]);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = cg * 8 + k;
+      acc[k] = leaky(acc[k] * scale[c] + shift[c], alpha);
+    }
+    *reinterpret_cast<uint4*>(y + (size_t)m * COUT + cg * 8) = pack8(acc);
+  }
+}
+
+// ---- weight packing: f32 HWIO -> bf16 [Cout][K] through a 64x64 LDS transpose ------
+__global__ __launch_bounds__(256) void pack_fwd_kernel(const float* w, bf16* out, int K, int Cout) {
+  __shared__ float t[64][65];
+  const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int kk = i / 64, nn = i % 64;
+    float v = 0.f;
+    if (k0 + kk < K && n0 + nn < Cout) v = w[(size_t)(k0 + kk) * Cout + n0 + nn];
+    t[kk][nn] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int nn = i / 64, kk = i % 64;
+    if (k0 + kk < K && n0 + nn < Cout) out[(size_t)(n0 + nn) * K + k0 + kk] = (bf16)t[kk][nn];
+  }
+}
+// dgrad operand: out[ci][tap'][co_pad] = w[taps-1-tap'][ci][co]   (co >= Cout -> 0)
+__global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* w, bf16* out, int taps, int Cin, int Cout,
+                                                         int cout_pad) {
+  const int64_t total = (int64_t)Cin * taps * cout_pad;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int co = (int)(i % cout_pad);
+    const int64_t r = i / cout_pad;
+    const int tp = (int)(r % taps);
+    const int ci = (int)(r / taps);
+    float v = 0.f;
+    if (co < Cout) v = w[((size_t)(taps - 1 - tp) * Cin + ci) * Cout + co];
+    out[i] = (bf16)v;
+  }
+}
+
+// ---- TF-form Adam (train_yolo3_mask.py:55) ------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, float* m, float* v, int64_t n,
+                                                   int64_t n_decay, float lr_t, float b1, float b2, float eps,
+                                                   float l2, float gscale) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float wi = w[i];
+    float gi = g[i] * gscale;
+    if (i < n_decay) gi += l2 * wi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    w[i] = wi - lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* w, int64_t n, float* part) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += w[i] * w[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void sumsq_final_kernel(const float* part, int nb, float coef, float* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < nb; ++i) s += (double)part[i];
+    out[0] = (float)(s * coef);
+  }
+}
+
+}  // namespace
+
+extern "C" int disyolo_conv_first_fwd(const float* images, const float* w_hwio, const float* scale,
+                                      const float* shift, void* y_bf16, int B, int H, int W, int Cout, float alpha,
+                                      void* stream) {
+  DY_REQUIRE(images && w_hwio && scale && shift && y_bf16 && B > 0 && H > 0 && W > 0, "conv_first: bad args");
+  DY_REQUIRE(Cout == 32, "conv_first: Cout must be 32 (got %d)", Cout);
+  const int64_t total = (int64_t)B * H * W * (Cout / 8);
+  int grid = ceil_div(total, 256);
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(conv_first_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, images, w_hwio, scale,
+                     shift, (bf16*)y_bf16, B, H, W, alpha);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+extern "C" int disyolo_pack_weights(const float* w_hwio, void* w_fwd, void* w_dgrad, int ksize, int Cin, int Cout,
+                                    int cout_pad, void* stream) {
+  DY_REQUIRE(w_hwio && (w_fwd || w_dgrad) && ksize > 0 && Cin > 0 && Cout > 0, "pack_weights: bad args");
+  DY_REQUIRE(!w_dgrad || cout_pad >= Cout, "pack_weights: cout_pad < Cout");
+  hipStream_t s = (hipStream_t)stream;
+  const int taps = ksize * ksize, K = taps * Cin;
+  if (w_fwd) {
+    hipLaunchKernelGGL(pack_fwd_kernel, dim3(ceil_div(K, 64), ceil_div(Cout, 64)), dim3(256), 0, s, w_hwio,
+                       (bf16*)w_fwd, K, Cout);
+    DY_CHECK_LAUNCH();
+  }
+  if (w_dgrad) {
+    const int64_t total = (int64_t)Cin * taps * cout_pad;
+    int grid = ceil_div(total, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid), dim3(256), 0, s, w_hwio, (bf16*)w_dgrad, taps, Cin, Cout,
+                       cout_pad);
+    DY_CHECK_LAUNCH();
+  }
+  return DISYOLO_OK;
+}
+
+extern "C" int disyolo_adam_step(float* w, const float* grad, float* m, float* v, int64_t n, int64_t n_decay, float lr,
+                                 float beta1, float beta2, float eps, float l2, int64_t t, float grad_scale,
+                                 void* stream) {
+  DY_REQUIRE(w && grad && m && v && n > 0 && t >= 1 && n_decay >= 0 && n_decay <= n, "adam: bad args");
+  const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
+  int grid = ceil_div(n, 256);
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, grad, m, v, n, n_decay,
+                     (float)lr_t, beta1, beta2, eps, l2, grad_scale);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+extern "C" size_t disyolo_l2_workspace(int64_t n) { return n > 0 ? 1024 * sizeof(float) : 0; }
+
+extern "C" int disyolo_l2_loss(const float* w, int64_t n, float l2, float* out, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  DY_REQUIRE(w && out && n > 0, "l2_loss: bad args");
+  if (!workspace || workspace_bytes < disyolo_l2_workspace(n)) {
+    disyolo_set_error("l2_loss: workspace too small");
+    return DISYOLO_E_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int nb = ceil_div(n, 256 * 8);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, s, w, n, (float*)workspace);
+  DY_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace, nb, 0.5f * l2, out);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}

@@ -1,0 +1,292 @@
+"""ctypes binding of the gfx950 kernel library (``include/disyolo.h``).
+
+There is no CPU fallback: if ``libdisyolo_hip.so`` is missing or an entry point
+returns an error, this module raises.  PyTorch is used only to own device memory
+and streams; kernels receive raw device pointers and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdisyolo_hip.so")
+
+GRAD_LD = 32
+ROI_MAX = 16
+ROI_W = 12
+CONV_LEAKY, CONV_OUT_F32, CONV_STATS = 1, 2, 4
+
+
+class DisyoloError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """mirror of ``disyolo_conv_desc`` (include/disyolo.h)"""
+    _fields_ = [
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("C0", C.c_int32), ("C1", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32),
+        ("ksize", C.c_int32), ("stride", C.c_int32),
+        ("pad_t", C.c_int32), ("pad_l", C.c_int32),
+        ("in_div", C.c_int32), ("flags", C.c_int32),
+        ("alpha", C.c_float), ("tile", C.c_int32),
+        ("x0", C.c_void_p), ("x1", C.c_void_p), ("w", C.c_void_p),
+        ("scale", C.c_void_p), ("shift", C.c_void_p), ("residual", C.c_void_p),
+        ("y", C.c_void_p), ("stats", C.c_void_p),
+    ]
+
+
+_SIGS = {
+    "disyolo_version": (C.c_int, []),
+    "disyolo_last_error": (C.c_char_p, []),
+    "disyolo_conv2d_stats_rows": (C.c_int, [C.POINTER(ConvDesc)]),
+    "disyolo_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "disyolo_conv_first_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
+    "disyolo_conv2d_wgrad_workspace": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "disyolo_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_size_t, C.c_void_p]),
+    "disyolo_conv_first_wgrad_workspace": (C.c_size_t, [C.c_int] * 4),
+    "disyolo_conv_first_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "disyolo_pack_weights": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
+    "disyolo_bn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64] + [C.c_void_p] * 4 +
+                            [C.c_float, C.c_float] + [C.c_void_p] * 5),
+    "disyolo_bn_fold": (C.c_int, [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 2 + [C.c_int, C.c_void_p]),
+    "disyolo_bn_act_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_float, C.c_void_p]),
+    "disyolo_bn_act_bwd_workspace": (C.c_size_t, [C.c_int64, C.c_int]),
+    "disyolo_bn_act_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t,
+                                                       C.c_void_p]),
+    "disyolo_upsample2x_bwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 7 + [C.c_void_p]),
+    "disyolo_colsum_workspace": (C.c_size_t, [C.c_int64, C.c_int]),
+    "disyolo_colsum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                 C.c_void_p]),
+    "disyolo_detect_workspace": (C.c_size_t, [C.c_int] * 3),
+    "disyolo_detect": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 2 + [C.c_float, C.c_float, C.c_int] +
+                       [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p]),
+    "disyolo_yolo_loss_workspace": (C.c_size_t, [C.c_int] * 3),
+    "disyolo_yolo_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_float] +
+                          [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]),
+    "disyolo_mask_rois": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 4 +
+                          [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "disyolo_psroi_loss_workspace": (C.c_size_t, [C.c_int, C.c_int]),
+    "disyolo_psroi_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 3 +
+                           [C.c_float] + [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p]),
+    "disyolo_psroi_assemble": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 3),
+    "disyolo_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int64] + [C.c_float] * 5 + [C.c_int64, C.c_float,
+                                                                                             C.c_void_p]),
+    "disyolo_l2_workspace": (C.c_size_t, [C.c_int64]),
+    "disyolo_l2_loss": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the kernel library; raises DisyoloError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DisyoloError(
+                "%s not found: build it with `make -C dis-yolo_amd/csrc` (or __graft_entry__.build()); "
+                "there is no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise DisyoloError("%s failed (%d): %s" % (what, rc, load().disyolo_last_error().decode()))
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need(t: torch.Tensor, dtype, name: str) -> None:
+    if t.dtype != dtype or not t.is_cuda or not t.is_contiguous():
+        raise DisyoloError("%s must be a contiguous CUDA tensor of %s (got %s on %s)" % (name, dtype, t.dtype, t.device))
+
+
+class Workspace:
+    """Grow-only device scratch buffer handed to the kernels that need one."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = torch.empty(1 << 20, dtype=torch.uint8, device=device)
+
+    def get(self, nbytes: int) -> torch.Tensor:
+        if self.buf.numel() < nbytes:
+            self.buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+def same_pads(size: int, k: int, s: int):
+    """TF 'SAME' geometry: (out, pad_before)."""
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    return out, total // 2
+
+
+def make_conv_desc(x0, w_packed, y, ksize, stride, *, x1=None, scale=None, shift=None, residual=None, stats=None,
+                   leaky=False, out_f32=False, alpha=0.1, tile=0, in_div=1, pads=None, out_hw=None) -> ConvDesc:
+    B, H, W, C0 = x0.shape
+    C1 = 0 if x1 is None else x1.shape[3]
+    if out_hw is None:
+        Ho, pt = same_pads(H, ksize, stride)
+        Wo, pl = same_pads(W, ksize, stride)
+    else:
+        Ho, Wo = out_hw
+        pt, pl = pads
+    if pads is not None:
+        pt, pl = pads
+    d = ConvDesc()
+    d.B, d.H, d.W, d.C0, d.C1 = B, H, W, C0, C1
+    d.Ho, d.Wo, d.Cout = Ho, Wo, y.shape[-1]
+    d.ksize, d.stride, d.pad_t, d.pad_l, d.in_div = ksize, stride, pt, pl, in_div
+    d.flags = (CONV_LEAKY if leaky else 0) | (CONV_OUT_F32 if out_f32 else 0) | (CONV_STATS if stats is not None else 0)
+    d.alpha, d.tile = alpha, tile
+    d.x0, d.x1, d.w = _p(x0), _p(x1), _p(w_packed)
+    d.scale, d.shift, d.residual = _p(scale), _p(shift), _p(residual)
+    d.y, d.stats = _p(y), _p(stats)
+    # the struct only holds raw pointers: keep the tensors alive as long as the descriptor
+    d._keepalive = (x0, x1, w_packed, scale, shift, residual, y, stats)
+    return d
+
+
+def conv2d_stats_rows(d: ConvDesc) -> int:
+    r = load().disyolo_conv2d_stats_rows(C.byref(d))
+    if r < 0:
+        raise DisyoloError("conv2d_stats_rows: bad descriptor")
+    return r
+
+
+def conv2d_fwd(d: ConvDesc) -> None:
+    _check(load().disyolo_conv2d_fwd(C.byref(d), _stream()), "conv2d_fwd")
+
+
+def conv_first_fwd(images, w_hwio, scale, shift, y, alpha=0.1) -> None:
+    _need(images, torch.float32, "images")
+    _need(y, torch.bfloat16, "y")
+    B, H, W, _ = images.shape
+    _check(load().disyolo_conv_first_fwd(_p(images), _p(w_hwio), _p(scale), _p(shift), _p(y), B, H, W, y.shape[-1],
+                                         alpha, _stream()), "conv_first_fwd")
+
+
+def conv2d_wgrad(d: ConvDesc, dy, dy_ld: int, dw, ws: Workspace) -> None:
+    need = load().disyolo_conv2d_wgrad_workspace(C.byref(d))
+    buf = ws.get(need)
+    _check(load().disyolo_conv2d_wgrad(C.byref(d), _p(dy), dy_ld, _p(dw), _p(buf), buf.numel(), _stream()),
+           "conv2d_wgrad")
+
+
+def conv_first_wgrad(images, dy, dw, ws: Workspace) -> None:
+    B, H, W, _ = images.shape
+    cout = dy.shape[-1]
+    need = load().disyolo_conv_first_wgrad_workspace(B, H, W, cout)
+    buf = ws.get(need)
+    _check(load().disyolo_conv_first_wgrad(_p(images), _p(dy), _p(dw), B, H, W, cout, _p(buf), buf.numel(), _stream()),
+           "conv_first_wgrad")
+
+
+def pack_weights(w_hwio, w_fwd, w_dgrad, ksize, cin, cout, cout_pad=0) -> None:
+    _check(load().disyolo_pack_weights(_p(w_hwio), _p(w_fwd), _p(w_dgrad), ksize, cin, cout, max(cout_pad, cout),
+                                       _stream()), "pack_weights")
+
+
+def bn_finalize(stats, rows, C_, count, gamma, beta, mm, mv, decay, eps, scale, shift, mean, rstd) -> None:
+    _check(load().disyolo_bn_finalize(_p(stats), rows, C_, count, _p(gamma), _p(beta), _p(mm), _p(mv), decay, eps,
+                                      _p(scale), _p(shift), _p(mean), _p(rstd), _stream()), "bn_finalize")
+
+
+def bn_fold(gamma, beta, mm, mv, eps, scale, shift) -> None:
+    _check(load().disyolo_bn_fold(_p(gamma), _p(beta), _p(mm), _p(mv), eps, _p(scale), _p(shift), gamma.numel(),
+                                  _stream()), "bn_fold")
+
+
+def bn_act_fwd(x, scale, shift, residual, y, rows, C_, alpha=0.1) -> None:
+    _check(load().disyolo_bn_act_fwd(_p(x), _p(scale), _p(shift), _p(residual), _p(y), rows, C_, alpha, _stream()),
+           "bn_act_fwd")
+
+
+def bn_act_bwd(dy, x, scale, shift, mean, rstd, dx, dgamma, dbeta, rows, C_, ws: Workspace, alpha=0.1) -> None:
+    need = load().disyolo_bn_act_bwd_workspace(rows, C_)
+    buf = ws.get(need)
+    _check(load().disyolo_bn_act_bwd(_p(dy), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(dx), _p(dgamma),
+                                     _p(dbeta), rows, C_, alpha, _p(buf), buf.numel(), _stream()), "bn_act_bwd")
+
+
+def upsample2x_bwd(src, dst, B, Hs, Ws, src_C, c_off, C_, accumulate=False) -> None:
+    _check(load().disyolo_upsample2x_bwd(_p(src), _p(dst), B, Hs, Ws, src_C, c_off, C_, int(accumulate), _stream()),
+           "upsample2x_bwd")
+
+
+def colsum(x, out, rows, C_, out_C, ws: Workspace) -> None:
+    need = load().disyolo_colsum_workspace(rows, C_)
+    buf = ws.get(need)
+    _check(load().disyolo_colsum(_p(x), _p(out), rows, C_, out_C, _p(buf), buf.numel(), _stream()), "colsum")
+
+
+def detect(logits3, logits2, logits1, B, S, num_class, anchors_host, clip_window, obj_thresh, nms_thresh, max_det,
+           detections, det_count, ws: Workspace) -> None:
+    need = load().disyolo_detect_workspace(B, S, num_class)
+    buf = ws.get(need)
+    anc = (C.c_float * 18)(*[float(v) for v in anchors_host])
+    _check(load().disyolo_detect(_p(logits3), _p(logits2), _p(logits1), B, S, num_class, anc, _p(clip_window),
+                                 obj_thresh, nms_thresh, max_det, _p(detections), _p(det_count), _p(buf), buf.numel(),
+                                 _stream()), "detect")
+
+
+def yolo_loss(logits, labels, true_boxes, max_boxes, B, S, num_class, anchors_host, ignore_thresh, scales, dlogits,
+              losses, ws: Workspace) -> None:
+    need = load().disyolo_yolo_loss_workspace(B, S, num_class)
+    buf = ws.get(need)
+    anc = (C.c_float * 18)(*[float(v) for v in anchors_host])
+    lg = (C.c_void_p * 3)(*[_p(t) for t in logits])
+    lb = (C.c_void_p * 3)(*[_p(t) for t in labels])
+    dl = (C.c_void_p * 3)(*[_p(t) for t in dlogits])
+    sc = (C.c_float * 4)(*[float(v) for v in scales])
+    _check(load().disyolo_yolo_loss(lg, lb, _p(true_boxes), max_boxes, B, S, num_class, anc, ignore_thresh, sc, dl,
+                                    _p(losses), _p(buf), buf.numel(), _stream()), "yolo_loss")
+
+
+def mask_rois(detections, max_det, true_boxes, G, perm_det, perm_gt, B, map_size, n_det, n_gt, iou_thresh, rois,
+              roi_count) -> None:
+    _check(load().disyolo_mask_rois(_p(detections), max_det, _p(true_boxes), G, _p(perm_det), _p(perm_gt), B, map_size,
+                                    n_det, n_gt, iou_thresh, _p(rois), _p(roi_count), _stream()), "mask_rois")
+
+
+def psroi_loss(score, true_masks, G, rois, roi_count, B, map_size, k, mask_scale, dscore, loss, ws: Workspace) -> None:
+    need = load().disyolo_psroi_loss_workspace(B, map_size)
+    buf = ws.get(need)
+    _check(load().disyolo_psroi_loss(_p(score), _p(true_masks), G, _p(rois), _p(roi_count), B, map_size, k, mask_scale,
+                                     _p(dscore), _p(loss), _p(buf), buf.numel(), _stream()), "psroi_loss")
+
+
+def psroi_assemble(score, detections, B, max_det, map_size, k, masks, keep) -> None:
+    _check(load().disyolo_psroi_assemble(_p(score), _p(detections), B, max_det, map_size, k, _p(masks), _p(keep),
+                                         _stream()), "psroi_assemble")
+
+
+def adam_step(w, grad, m, v, n, n_decay, lr, b1, b2, eps, l2, t, grad_scale=1.0) -> None:
+    _check(load().disyolo_adam_step(_p(w), _p(grad), _p(m), _p(v), n, n_decay, lr, b1, b2, eps, l2, t, grad_scale,
+                                    _stream()), "adam_step")
+
+
+def l2_loss(w, n, l2, out, ws: Workspace) -> None:
+    need = load().disyolo_l2_workspace(n)
+    buf = ws.get(need)
+    _check(load().disyolo_l2_loss(_p(w), n, l2, _p(out), _p(buf), buf.numel(), _stream()), "l2_loss")

@@ -1,0 +1,197 @@
+/*
+ * disyolo.h -- C ABI of the MI355X (gfx950) kernel library for the DIS-YOLO hot path.
+ *
+ * The reference (ZHANGKEON/DIS-YOLO) has no FFI/plugin interface: its hot path is a
+ * TensorFlow-1.x graph (yolo/yolo3_net_pos.py) driven through tf.Session.run.  Each
+ * entry point below replaces the TF op call sites named in its comment (file:line in
+ * the reference checkout).  A maintainer binds them with ctypes.
+ *
+ * Conventions
+ *   - extern "C", plain pointers + sizes; no torch / C++ types.
+ *   - every pointer is a DEVICE pointer unless stated; `stream` is a hipStream_t
+ *     passed as void*.  Calls are stream-ordered, never synchronise, never allocate
+ *     (graph-capture safe); scratch comes from caller-provided workspaces.
+ *   - return 0 on success, a negative DISYOLO_E_* code otherwise.  Nothing throws or
+ *     exits.  disyolo_last_error() returns a static message for the calling thread.
+ *   - activations are NHWC bf16; logits / score maps / losses / statistics are f32;
+ *     master weights are f32 HWIO [k,k,Cin,Cout] (the reference checkpoint layout,
+ *     yolo/yolo3_net_pos.py:112,118); the MFMA kernels read a packed bf16 copy made
+ *     by disyolo_pack_weights.
+ */
+#ifndef DISYOLO_H
+#define DISYOLO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DISYOLO_OK 0
+#define DISYOLO_E_ARG (-1)      /* invalid argument / unsupported shape */
+#define DISYOLO_E_WORKSPACE (-2) /* workspace too small */
+#define DISYOLO_E_HIP (-3)      /* a HIP runtime call failed */
+
+#define DISYOLO_GRAD_LD 32      /* channel pitch of the head-logit / score-map gradients */
+#define DISYOLO_ROI_MAX 16      /* RoI slots per image in the mask-loss RoI table       */
+#define DISYOLO_ROI_W 12        /* int32 words per RoI: gy0..3, gx0..3, gt_row, area, valid, 0 */
+
+int disyolo_version(void);
+const char* disyolo_last_error(void);
+
+/* ---- convolution (replaces tf.nn.conv2d + bias_add + folded batch_normalization +
+ *      leaky_relu + residual add + resize_nearest_neighbor/concat feeding a 1x1 conv:
+ *      yolo/yolo3_net_pos.py:125-129,142-145,150,290-291,325-326,386-387,401-402) ---- */
+enum {
+  DISYOLO_CONV_LEAKY = 1,       /* y = max(alpha*y, y) after scale/shift            */
+  DISYOLO_CONV_OUT_F32 = 2,     /* y is f32 (head logits / score maps), else bf16    */
+  DISYOLO_CONV_STATS = 4        /* also emit per-channel (sum, sum of squares) of the
+                                   raw accumulators into `stats` (training BN, :90)  */
+};
+
+typedef struct disyolo_conv_desc {
+  int32_t B, H, W;        /* source-0 spatial size                                   */
+  int32_t C0, C1;         /* channels of source 0 / source 1 (C1 = 0: single source) */
+  int32_t Ho, Wo, Cout;   /* output size                                              */
+  int32_t ksize, stride;  /* 1 or 3; 1 or 2                                           */
+  int32_t pad_t, pad_l;   /* TF 'SAME' leading pads (asymmetric for k=3,s=2)          */
+  int32_t in_div;         /* 1 = forward gather.  s>1 = transposed gather for the
+                             data-gradient of a stride-s conv: a tap contributes only
+                             where (yo*stride + kh - pad_t) is divisible by in_div    */
+  int32_t flags;          /* DISYOLO_CONV_*                                           */
+  float alpha;            /* leaky slope                                              */
+  int32_t tile;           /* 0 = auto; else tile-config id (tuning/testing)          */
+  const void* x0;         /* bf16 [B,H,W,C0]                                          */
+  const void* x1;         /* bf16 [B,H/2,W/2,C1]: nearest-upsampled x2 and concatenated
+                             after x0 along channels (1x1 convs only), or NULL        */
+  const void* w;          /* bf16 packed [Cout][ksize*ksize*(C0+C1)], k = (kh,kw,ci) */
+  const float* scale;     /* [Cout] or NULL (=1)                                      */
+  const float* shift;     /* [Cout] or NULL (=0)  (folded BN beta / conv bias)        */
+  const void* residual;   /* bf16 [B,Ho,Wo,Cout] added after the activation, or NULL  */
+  void* y;                /* bf16 or f32 [B,Ho,Wo,Cout]                               */
+  float* stats;           /* f32 [disyolo_conv2d_stats_rows][Cout][2] or NULL         */
+} disyolo_conv_desc;
+
+/* rows of the `stats` partial buffer a call with this descriptor writes */
+int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d);
+int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream);
+
+/* first layer (Cin=3, k=3, s=1; yolo/yolo3_net_pos.py:159): f32 NHWC image in, exact f32
+ * FMA with the f32 HWIO weights, folded BN + leaky, bf16 out. */
+int disyolo_conv_first_fwd(const float* images, const float* w_hwio, const float* scale,
+                           const float* shift, void* y_bf16, int B, int H, int W, int Cout,
+                           float alpha, void* stream);
+
+/* weight gradient (TF autodiff of tf.nn.conv2d wrt filters; train_yolo3_mask.py:55):
+ * dw[kh,kw,ci,co] (f32 HWIO, overwritten) = sum_m xcol[m,(kh,kw,ci)] * dy[m,co].
+ * Uses d->x0/x1 (the layer input, same gather as forward) and `dy` bf16 [B*Ho*Wo, dy_ld]
+ * (dy_ld >= Cout, multiple of 8; columns >= Cout are ignored).
+ * workspace: disyolo_conv2d_wgrad_workspace(d) bytes. */
+size_t disyolo_conv2d_wgrad_workspace(const disyolo_conv_desc* d);
+int disyolo_conv2d_wgrad(const disyolo_conv_desc* d, const void* dy, int dy_ld, float* dw,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* same for the first layer (f32 image input, Cin = 3): dw f32 [3,3,3,Cout] */
+size_t disyolo_conv_first_wgrad_workspace(int B, int H, int W, int Cout);
+int disyolo_conv_first_wgrad(const float* images, const void* dy, float* dw, int B, int H, int W,
+                             int Cout, void* workspace, size_t workspace_bytes, void* stream);
+
+/* f32 HWIO master -> packed bf16 operands.  w_fwd [Cout][k*k*Cin] (may be NULL); w_dgrad
+ * (may be NULL) [Cin][k*k*cout_pad] with taps flipped and zero columns for co >= Cout, i.e.
+ * the forward operand of the data-gradient conv over a dy padded to cout_pad channels. */
+int disyolo_pack_weights(const float* w_hwio, void* w_fwd, void* w_dgrad, int ksize, int Cin,
+                         int Cout, int cout_pad, void* stream);
+
+/* ---- batch normalisation (yolo/yolo3_net_pos.py:71-107) ---- */
+/* stats partials -> batch mean / population variance; scale = gamma*rsqrt(var+eps),
+ * shift = beta - mean*scale; moving <- decay*moving + (1-decay)*batch (:93-96). */
+int disyolo_bn_finalize(const float* stats, int rows, int C, int64_t count, const float* gamma,
+                        const float* beta, float* moving_mean, float* moving_var, float decay,
+                        float eps, float* scale, float* shift, float* mean, float* rstd,
+                        void* stream);
+/* locked / inference BN folded to scale/shift from the moving statistics (:81,:101) */
+int disyolo_bn_fold(const float* gamma, const float* beta, const float* moving_mean,
+                    const float* moving_var, float eps, float* scale, float* shift, int C,
+                    void* stream);
+/* y = leaky(x*scale + shift) [+ residual], bf16 [rows,C] */
+int disyolo_bn_act_fwd(const void* x, const float* scale, const float* shift, const void* residual,
+                       void* y, int64_t rows, int C, float alpha, void* stream);
+/* backward of y = leaky(gamma*xhat + beta), training statistics.  dy, x bf16 [rows,C];
+ * writes dx bf16 and dgamma/dbeta f32.  workspace: disyolo_bn_act_bwd_workspace bytes. */
+size_t disyolo_bn_act_bwd_workspace(int64_t rows, int C);
+int disyolo_bn_act_bwd(const void* dy, const void* x, const float* scale, const float* shift,
+                       const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                       int64_t rows, int C, float alpha, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* ---- small data-movement ops of the backward pass ---- */
+/* dst[b,y,x,c] = sum of the 2x2 block of src (gradient of resize_nearest_neighbor x2),
+ * reading channels [c_off, c_off+C) of a src row of src_C channels; bf16. */
+int disyolo_upsample2x_bwd(const void* src, void* dst, int B, int Hs, int Ws, int src_C, int c_off,
+                           int C, int accumulate, void* stream);
+/* column sums of a bf16 [rows,C] matrix -> f32 out[0:out_C] (bias gradient; out_C <= C) */
+size_t disyolo_colsum_workspace(int64_t rows, int C);
+int disyolo_colsum(const void* x, float* out, int64_t rows, int C, int out_C, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* ---- detection decode + filter (interpret_output / filter_detections,
+ *      yolo/yolo3_net_pos.py:465-628,940-952) ---- */
+/* logits: three f32 tensors [B,g,g,3,5+C] in the reference's scale order (S/8, S/16, S/32
+ * grids).  anchors: host pointer to 18 floats (w,h)x9 in pixels.  Writes detections f32
+ * [B,max_det,6] rows (y1,x1,y2,x2,classid,score), score-descending, zero padded, and
+ * det_count int32 [B].  workspace: disyolo_detect_workspace bytes. */
+size_t disyolo_detect_workspace(int B, int S, int num_class);
+int disyolo_detect(const float* logits3, const float* logits2, const float* logits1, int B, int S,
+                   int num_class, const float* anchors_host, const float* clip_window,
+                   float obj_thresh, float nms_thresh, int max_det, float* detections,
+                   int32_t* det_count, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- YOLO loss + gradient (loss_yolo, yolo/yolo3_net_pos.py:631-747) ---- */
+/* labels: f32 [B,g,g,3,5+C] per scale (yolo3, yolo2, yolo1); true_boxes f32 [B,20,5].
+ * dlogits: bf16 [B,g,g,32] per scale = d(loss)/d(logits) (already divided by B), rows padded
+ * with zeros from 3*(5+C) to 32 channels (DISYOLO_GRAD_LD) so they feed the MFMA convs.
+ * losses f32[8]: obj, noobj, class, xy, wh, (conf, coord, yolo_total). */
+size_t disyolo_yolo_loss_workspace(int B, int S, int num_class);
+int disyolo_yolo_loss(const float* const logits[3], const float* const labels[3],
+                      const float* true_boxes, int max_boxes, int B, int S, int num_class,
+                      const float* anchors_host, float ignore_thresh, const float scales[4],
+                      void* const dlogits[3], float* losses, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* ---- position-sensitive RoI assembly (yolo/yolo3_net_pos.py:750-938) ---- */
+/* RoI selection for the mask loss (:757-796): detections [B,max_det,6], true_boxes [B,G,5],
+ * perm_det int32 [B,max_det] / perm_gt int32 [B,G] replace tf.random_shuffle (:781-782).
+ * Writes rois int32 [B,DISYOLO_ROI_MAX,DISYOLO_ROI_W] (positive RoIs first: the k+1 bin edges
+ * per axis on the S/2 grid after tf.round, assigned GT row, pixel area) and roi_count [B]. */
+int disyolo_mask_rois(const float* detections, int max_det, const float* true_boxes, int G,
+                      const int32_t* perm_det, const int32_t* perm_gt, int B, int map_size,
+                      int n_det, int n_gt, float iou_thresh, int32_t* rois, int32_t* roi_count,
+                      void* stream);
+/* masked BCE over assembled logits + gradient wrt the score maps (:799-858).
+ * score f32 [B,Sm,Sm,k*k]; true_masks uint8 [B,G,2Sm,2Sm]; dscore bf16 [B,Sm,Sm,32] (padded);
+ * loss f32[1] = mask_scale * mean_b(mean_r(sum BCE / area)). */
+size_t disyolo_psroi_loss_workspace(int B, int map_size);
+int disyolo_psroi_loss(const float* score, const uint8_t* true_masks, int G, const int32_t* rois,
+                       const int32_t* roi_count, int B, int map_size, int k, float mask_scale,
+                       void* dscore, float* loss, void* workspace, size_t workspace_bytes,
+                       void* stream);
+/* inference assembly (val_test, :862-938): masks f32 [B,max_det,Sm,Sm] = sigmoid(selected
+ * channel) inside the box, 0.5 outside; keep int32 [B,max_det] = 1 for rows with h>0 and w>0. */
+int disyolo_psroi_assemble(const float* score, const float* detections, int B, int max_det,
+                           int map_size, int k, float* masks, int32_t* keep, void* stream);
+
+/* ---- optimizer (tf.train.AdamOptimizer.minimize, train_yolo3_mask.py:55) ---- */
+/* TF-form Adam on a flat f32 arena; elements [0, n_decay) also receive the gradient of the
+ * l2 regulariser (grad += l2*w; yolo/yolo3_net_pos.py:38).  step t >= 1. */
+int disyolo_adam_step(float* w, const float* grad, float* m, float* v, int64_t n, int64_t n_decay,
+                      float lr, float beta1, float beta2, float eps, float l2, int64_t t,
+                      float grad_scale, void* stream);
+/* 0.5*l2*sum(w[0:n]^2) -> out f32[1] (only needed when the loss value is logged) */
+size_t disyolo_l2_workspace(int64_t n);
+int disyolo_l2_loss(const float* w, int64_t n, float l2, float* out, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISYOLO_H */

@@ -1,0 +1,259 @@
+"""GPU parity of the implicit-GEMM convolution family against the CPU oracle.
+
+Tolerances: inputs/weights are rounded to bf16 once and shared by both sides, the
+oracle computes in f64, the kernels accumulate in f32 on MFMA and (unless OUT_F32)
+round the result to bf16.  bf16 has 8 significant bits, so |err| <= 2^-8 |y| + a small
+absolute term for the f32 accumulation; f32 outputs are held to 1e-4 relative to the
+largest output magnitude.
+"""
+import numpy as np
+import pytest
+import torch
+
+import disyolo_oracle as O
+from disyolo_amd import lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def bf16r(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+def pack_ref(w_hwio):
+    k, _, cin, cout = w_hwio.shape
+    return w_hwio.permute(3, 0, 1, 2).reshape(cout, k * k * cin).contiguous()
+
+
+def check(got, want, rel, abs_):
+    got = got.double().cpu()
+    want = want.detach().double()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert torch.isfinite(got).all(), "non-finite values in kernel output"
+    err = (got - want).abs()
+    tol = rel * want.abs() + abs_
+    excess = (err - tol).flatten()
+    i = int(excess.argmax())
+    assert excess[i] <= 0, "err %.4g > tol %.4g (%d of %d elems out of tolerance; max|want| %.4g)" % (
+        float(err.flatten()[i]), float(tol.flatten()[i]), int((excess > 0).sum()), excess.numel(), float(want.abs().max()))
+
+
+CASES = [
+    # B, H, W, Cin, Cout, k, s, tile
+    (2, 18, 18, 64, 128, 3, 1, 0),
+    (2, 18, 18, 64, 128, 3, 1, 1),
+    (2, 18, 18, 64, 128, 3, 1, 3),
+    (1, 20, 20, 32, 64, 3, 2, 0),      # asymmetric SAME pads
+    (1, 20, 20, 32, 64, 3, 2, 6),
+    (2, 17, 19, 32, 64, 3, 2, 2),      # odd sizes: symmetric pads, ragged M
+    (2, 12, 12, 128, 32, 1, 1, 0),
+    (2, 12, 12, 96, 32, 1, 1, 4),
+    (1, 40, 40, 64, 64, 3, 1, 7),
+    (3, 9, 9, 256, 256, 3, 1, 0),
+    (1, 16, 16, 1024, 512, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,tile", CASES)
+def test_conv_fwd_matches_oracle(dev, B, H, W, Cin, Cout, k, s, tile):
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cin + Cout + k + s + tile)
+    x = bf16r(torch.randn(B, H, W, Cin, generator=g))
+    w = bf16r(torch.randn(k, k, Cin, Cout, generator=g) / (k * k * Cin) ** 0.5)
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    want_raw = O.conv2d_same(x, w, s)
+    want = O.leaky_relu(want_raw * scale.double() + shift.double(), 0.1)
+    xd = x.to(torch.bfloat16).to(dev)
+    wd = pack_ref(w).to(torch.bfloat16).to(dev)
+    y = torch.empty(B, want.shape[1], want.shape[2], Cout, dtype=torch.bfloat16, device=dev)
+    d = L.make_conv_desc(xd, wd, y, k, s, scale=scale.to(dev), shift=shift.to(dev), leaky=True, tile=tile)
+    L.conv2d_fwd(d)
+    torch.cuda.synchronize()
+    check(y, want, 2.0 ** -7, 1e-3)
+
+
+def test_conv_identity_asymmetric(dev):
+    """A = I check with an asymmetric operand (cdna guide s3): 1x1 conv with identity
+    weights must reproduce the input exactly; catches row/col swaps in the MFMA maps."""
+    B, H, W, Cch = 1, 16, 16, 128
+    x = (torch.arange(B * H * W * Cch, dtype=torch.float32).reshape(B, H, W, Cch) % 251) - 125
+    w = torch.eye(Cch).reshape(1, 1, Cch, Cch)
+    xd = x.to(torch.bfloat16).to(dev)
+    wd = pack_ref(w).to(torch.bfloat16).to(dev)
+    y = torch.empty(B, H, W, Cch, dtype=torch.float32, device=dev)
+    d = L.make_conv_desc(xd, wd, y, 1, 1, out_f32=True)
+    L.conv2d_fwd(d)
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), x)
+
+
+def test_conv_out_f32_bias_small_n(dev):
+    """head-style conv: 1x1, bias, linear, f32 out, Cout = 24 and 9 (ragged N)."""
+    for Cout, tile in ((24, 0), (9, 0), (9, 4)):
+        g = torch.Generator().manual_seed(Cout)
+        x = bf16r(torch.randn(2, 18, 18, 256, generator=g))
+        w = bf16r(torch.randn(1, 1, 256, Cout, generator=g) / 16)
+        bias = torch.randn(Cout, generator=g)
+        want = O.conv2d_same(x, w, 1) + bias.double()
+        y = torch.empty(2, 18, 18, Cout, dtype=torch.float32, device=dev)
+        d = L.make_conv_desc(x.to(torch.bfloat16).to(dev), pack_ref(w).to(torch.bfloat16).to(dev), y, 1, 1,
+                             shift=bias.to(dev), out_f32=True, tile=tile)
+        L.conv2d_fwd(d)
+        torch.cuda.synchronize()
+        check(y, want, 1e-5, 1e-4 * float(want.abs().max()))
+
+
+def test_conv_residual_and_fused_concat(dev):
+    g = torch.Generator().manual_seed(7)
+    # residual (res_conv_bn, yolo/yolo3_net_pos.py:148-151): add AFTER the activation
+    x = bf16r(torch.randn(2, 18, 18, 64, generator=g))
+    w = bf16r(torch.randn(3, 3, 64, 128, generator=g) / 24)
+    res = bf16r(torch.randn(2, 18, 18, 128, generator=g))
+    want = O.leaky_relu(O.conv2d_same(x, w, 1), 0.1) + res
+    y = torch.empty(2, 18, 18, 128, dtype=torch.bfloat16, device=dev)
+    d = L.make_conv_desc(x.to(torch.bfloat16).to(dev), pack_ref(w).to(torch.bfloat16).to(dev), y, 3, 1,
+                         residual=res.to(torch.bfloat16).to(dev), leaky=True)
+    L.conv2d_fwd(d)
+    torch.cuda.synchronize()
+    check(y, want, 2.0 ** -7, 1e-3)
+    # fused nearest-upsample + concat [skip, up] feeding a 1x1 conv (:290-293)
+    skip = bf16r(torch.randn(2, 12, 12, 64, generator=g))
+    low = bf16r(torch.randn(2, 6, 6, 32, generator=g))
+    w = bf16r(torch.randn(1, 1, 96, 32, generator=g) / 10)
+    cat = torch.cat([skip, O.upsample2(low)], dim=-1)
+    want = O.conv2d_same(cat, w, 1)
+    y = torch.empty(2, 12, 12, 32, dtype=torch.bfloat16, device=dev)
+    d = L.make_conv_desc(skip.to(torch.bfloat16).to(dev), pack_ref(w).to(torch.bfloat16).to(dev), y, 1, 1,
+                         x1=low.to(torch.bfloat16).to(dev))
+    L.conv2d_fwd(d)
+    torch.cuda.synchronize()
+    check(y, want, 2.0 ** -7, 1e-3)
+
+
+def test_conv_stats_and_bn_finalize(dev):
+    """training BN: stats epilogue + finalize == tf.nn.moments (population variance) and the
+    moving-average update of yolo/yolo3_net_pos.py:90-98."""
+    g = torch.Generator().manual_seed(11)
+    B, H, W, Cin, Cout = 2, 18, 18, 64, 128
+    x = bf16r(torch.randn(B, H, W, Cin, generator=g))
+    w = bf16r(torch.randn(3, 3, Cin, Cout, generator=g) / 24)
+    raw = O.conv2d_same(x, w, 1)
+    y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=dev)
+    d = L.make_conv_desc(x.to(torch.bfloat16).to(dev), pack_ref(w).to(torch.bfloat16).to(dev), y, 3, 1)
+    rows = L.conv2d_stats_rows(d)
+    stats = torch.zeros(rows, Cout, 2, dtype=torch.float32, device=dev)
+    d = L.make_conv_desc(x.to(torch.bfloat16).to(dev), pack_ref(w).to(torch.bfloat16).to(dev), y, 3, 1, stats=stats)
+    L.conv2d_fwd(d)
+    gamma = (torch.rand(Cout, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    mm = torch.zeros(Cout, device=dev)
+    mv = torch.ones(Cout, device=dev)
+    scale, shift, mean, rstd = (torch.empty(Cout, device=dev) for _ in range(4))
+    L.bn_finalize(stats, rows, Cout, B * H * W, gamma, beta, mm, mv, 0.997, 1e-5, scale, shift, mean, rstd)
+    act = torch.empty_like(y)
+    L.bn_act_fwd(y, scale, shift, None, act, B * H * W, Cout)
+    torch.cuda.synchronize()
+    m = raw.mean(dim=(0, 1, 2))
+    v = ((raw - m) ** 2).mean(dim=(0, 1, 2))
+    check(mean, m, 1e-4, 1e-5)
+    check(rstd, 1 / torch.sqrt(v + 1e-5), 1e-4, 1e-5)
+    check(mm, 0.003 * m, 1e-4, 1e-6)
+    check(mv, 0.997 + 0.003 * v, 1e-4, 1e-6)
+    want = O.leaky_relu((raw - m) / torch.sqrt(v + 1e-5) * gamma.cpu().double() + beta.cpu().double(), 0.1)
+    check(act, want, 2.0 ** -6, 2e-2)
+
+
+def test_conv_first_layer(dev):
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 20, 24, 3, generator=g)
+    w = torch.randn(3, 3, 3, 32, generator=g) * 0.2
+    scale = torch.rand(32, generator=g) + 0.5
+    shift = torch.randn(32, generator=g) * 0.1
+    want = O.leaky_relu(O.conv2d_same(x.double(), w.double(), 1) * scale.double() + shift.double(), 0.1)
+    y = torch.empty(2, 20, 24, 32, dtype=torch.bfloat16, device=dev)
+    L.conv_first_fwd(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev), y)
+    torch.cuda.synchronize()
+    check(y, want, 2.0 ** -8, 1e-5)
+
+
+def test_pack_weights(dev):
+    g = torch.Generator().manual_seed(5)
+    for k, cin, cout, pad in ((3, 64, 128, 128), (1, 96, 24, 32), (3, 32, 9, 32)):
+        w = torch.randn(k, k, cin, cout, generator=g)
+        wf = torch.empty(cout, k * k * cin, dtype=torch.bfloat16, device=dev)
+        wdg = torch.empty(cin, k * k * pad, dtype=torch.bfloat16, device=dev)
+        L.pack_weights(w.to(dev), wf, wdg, k, cin, cout, pad)
+        torch.cuda.synchronize()
+        assert torch.equal(wf.cpu(), pack_ref(w).to(torch.bfloat16))
+        ref = torch.zeros(cin, k, k, pad)
+        ref[..., :cout] = w.flip(0, 1).permute(2, 0, 1, 3)
+        assert torch.equal(wdg.cpu(), ref.reshape(cin, -1).to(torch.bfloat16))
+
+
+DGRAD = [(2, 18, 18, 64, 128, 3, 1), (2, 12, 12, 128, 64, 1, 1), (1, 20, 20, 32, 64, 3, 2), (2, 17, 19, 32, 64, 3, 2)]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s", DGRAD)
+def test_conv_dgrad_matches_autograd(dev, B, H, W, Cin, Cout, k, s):
+    """data gradient = forward kernel over dy with the flipped/transposed operand made by
+    pack_weights, pads k-1-pad, and the transposed gather (in_div = stride)."""
+    g = torch.Generator().manual_seed(Cin + Cout + k + s)
+    x = torch.randn(B, H, W, Cin, generator=g, dtype=torch.float64, requires_grad=True)
+    w = bf16r(torch.randn(k, k, Cin, Cout, generator=g) / (k * k * Cin) ** 0.5)
+    y = O.conv2d_same(x, w, s)
+    dy = bf16r(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    want = x.grad
+    Ho, pt, _ = O.same_pads(H, k, s)
+    Wo, pl, _ = O.same_pads(W, k, s)
+    wdg = torch.empty(Cin, k * k * Cout, dtype=torch.bfloat16, device=dev)
+    L.pack_weights(w.float().to(dev), None, wdg, k, Cin, Cout, Cout)
+    dx = torch.empty(B, H, W, Cin, dtype=torch.bfloat16, device=dev)
+    d = L.make_conv_desc(dy.to(torch.bfloat16).to(dev), wdg, dx, k, 1, in_div=s, pads=(k - 1 - pt, k - 1 - pl),
+                         out_hw=(H, W))
+    L.conv2d_fwd(d)
+    torch.cuda.synchronize()
+    check(dx, want, 2.0 ** -7, 2e-3)
+
+
+WGRAD = [(2, 18, 18, 64, 128, 3, 1), (2, 12, 12, 128, 64, 1, 1), (1, 20, 20, 32, 64, 3, 2), (2, 18, 18, 256, 24, 1, 1),
+         (1, 24, 24, 64, 9, 1, 1), (3, 10, 10, 96, 32, 1, 1), (2, 36, 36, 32, 64, 3, 1)]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s", WGRAD)
+def test_conv_wgrad_matches_autograd(dev, B, H, W, Cin, Cout, k, s):
+    g = torch.Generator().manual_seed(Cin * 3 + Cout + k + s)
+    x = bf16r(torch.randn(B, H, W, Cin, generator=g))
+    w = torch.randn(k, k, Cin, Cout, generator=g, dtype=torch.float64, requires_grad=True)
+    y = O.conv2d_same(x, w, s)
+    dy = bf16r(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    want = w.grad
+    ld = ((Cout + 31) // 32) * 32 if Cout % 8 else Cout
+    dyp = torch.zeros(y.shape[0], y.shape[1], y.shape[2], ld, dtype=torch.bfloat16, device=dev)
+    dyp[..., :Cout] = dy.to(torch.bfloat16).to(dev)
+    dw = torch.full((k, k, Cin, Cout), float("nan"), dtype=torch.float32, device=dev)
+    dummy = torch.empty(1, dtype=torch.bfloat16, device=dev)
+    yd = torch.empty(y.shape, dtype=torch.bfloat16, device=dev)
+    d = L.make_conv_desc(x.to(torch.bfloat16).to(dev), dummy, yd, k, s)
+    L.conv2d_wgrad(d, dyp, ld, dw, L.Workspace(dev))
+    torch.cuda.synchronize()
+    check(dw, want, 1e-4, 2e-4 * float(want.abs().max()))
+
+
+def test_wgrad_fused_concat(dev):
+    g = torch.Generator().manual_seed(9)
+    skip = bf16r(torch.randn(2, 12, 12, 64, generator=g))
+    low = bf16r(torch.randn(2, 6, 6, 32, generator=g))
+    w = torch.randn(1, 1, 96, 32, generator=g, dtype=torch.float64, requires_grad=True)
+    cat = torch.cat([skip, O.upsample2(low)], dim=-1)
+    y = O.conv2d_same(cat, w, 1)
+    dy = bf16r(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    dw = torch.empty(1, 1, 96, 32, dtype=torch.float32, device=dev)
+    dummy = torch.empty(1, dtype=torch.bfloat16, device=dev)
+    yd = torch.empty(y.shape, dtype=torch.bfloat16, device=dev)
+    d = L.make_conv_desc(skip.to(torch.bfloat16).to(dev), dummy, yd, 1, 1, x1=low.to(torch.bfloat16).to(dev))
+    L.conv2d_wgrad(d, dy.to(torch.bfloat16).to(dev), 32, dw, L.Workspace(dev))
+    torch.cuda.synchronize()
+    check(dw, w.grad, 1e-4, 2e-4 * float(w.grad.abs().max()))
