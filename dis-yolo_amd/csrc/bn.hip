@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const uint4* x, const f
 // C/8 <= 256; wider matrices are covered by gridDim.y column blocks of 2048 channels.
 // MODE 0: sum(x)            (bias gradient)
 // MODE 1: sum(g), sum(g*xhat) with g = dy*act'(x*scale+shift)   (BN backward)
+// MODE 2: sum(x), sum(x^2)  (batch statistics of an already materialised conv output)
 template <int MODE>
 __global__ __launch_bounds__(256) void colreduce_kernel(const uint4* a, const uint4* b, const float* scale,
                                                         const float* shift, const float* mean, const float* rstd,
@@ -150,6 +151,12 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const uint4* a, const ui
       if (MODE == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] += va[k];
+      } else if (MODE == 2) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          acc[k] += va[k];
+          acc[8 + k] += va[k] * va[k];
+        }
       } else {
         float vx[8];
         unpack8(b[r * chunks + chunk], vx);
@@ -381,6 +388,22 @@ extern "C" int disyolo_colsum(const void* x, float* out, int64_t rows, int C, in
   DY_CHECK_LAUNCH();
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, s, (const float*)workspace, nb, C,
                      out_C, out);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+extern "C" int disyolo_colstats_rows(int64_t rows, int C) {
+  if (rows <= 0 || C <= 0 || C % 8) return DISYOLO_E_ARG;
+  return colreduce_blocks(rows, C);
+}
+
+extern "C" int disyolo_colstats(const void* x, float* stats, int64_t rows, int C, void* stream) {
+  DY_REQUIRE(x && stats && rows > 0 && C > 0 && C % 8 == 0, "colstats: bad args (C %% 8 == 0)");
+  const int nb = colreduce_blocks(rows, C), rpb = colreduce_rpb(rows, C);
+  const int chunks = C / 8, cpb = chunks < 256 ? chunks : 256;
+  hipLaunchKernelGGL(colreduce_kernel<2>, dim3(nb, ceil_div(chunks, cpb)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)x, (const uint4*)nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, rows, C, rpb,
+                     stats);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }

@@ -55,6 +55,8 @@ _SIGS = {
     "disyolo_pack_weights": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
     "disyolo_bn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64] + [C.c_void_p] * 4 +
                             [C.c_float, C.c_float] + [C.c_void_p] * 5),
+    "disyolo_colstats_rows": (C.c_int, [C.c_int64, C.c_int]),
+    "disyolo_colstats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "disyolo_bn_fold": (C.c_int, [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 2 + [C.c_int, C.c_void_p]),
     "disyolo_bn_act_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_float, C.c_void_p]),
     "disyolo_bn_act_bwd_workspace": (C.c_size_t, [C.c_int64, C.c_int]),
@@ -210,6 +212,17 @@ def pack_weights(w_hwio, w_fwd, w_dgrad, ksize, cin, cout, cout_pad=0) -> None:
 def bn_finalize(stats, rows, C_, count, gamma, beta, mm, mv, decay, eps, scale, shift, mean, rstd) -> None:
     _check(load().disyolo_bn_finalize(_p(stats), rows, C_, count, _p(gamma), _p(beta), _p(mm), _p(mv), decay, eps,
                                       _p(scale), _p(shift), _p(mean), _p(rstd), _stream()), "bn_finalize")
+
+
+def colstats_rows(rows, C_) -> int:
+    r = load().disyolo_colstats_rows(rows, C_)
+    if r < 0:
+        raise DisyoloError("colstats_rows: bad shape")
+    return r
+
+
+def colstats(x, stats, rows, C_) -> None:
+    _check(load().disyolo_colstats(_p(x), _p(stats), rows, C_, _stream()), "colstats")
 
 
 def bn_fold(gamma, beta, mm, mv, eps, scale, shift) -> None:

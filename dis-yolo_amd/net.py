@@ -1,0 +1,622 @@
+"""Host-side mirror of the reference's ``YOLONet`` (yolo/yolo3_net_pos.py:12-65).
+
+The TF-1.x graph object becomes a plan over the gfx950 kernel library: the 82-layer
+topology (yolo/yolo3_net_pos.py:159-412) is a data table, every layer is one or two
+kernel launches through the C ABI (``lib.py``), and PyTorch only owns device memory,
+streams and (for data parallel training) the RCCL process group.
+
+Same constructor / attribute names as the reference where they exist:
+``YOLONet(training)``, ``batchsize``, ``classes``, ``num_class``, ``anchors``,
+``num_anchor``, ``output_depth``, ``k``, ``k_mapout``, ``*_scale``.  ``sess.run``
+fetches become methods: ``forward`` (= ``logits``), ``evaluation``, ``train_step``
+(= ``[total_loss, optimizer]``).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import math
+import numpy as np
+import torch
+
+from . import config as cfg
+from . import lib as L
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+class Layer:
+    __slots__ = ("idx", "cin", "cout", "k", "stride", "kind", "src", "src_up", "shortcut", "lock", "H", "W", "Ho",
+                 "Wo", "w", "bias", "gamma", "beta", "mm", "mv", "scale", "shift", "mean", "rstd", "wp", "wdg", "raw",
+                 "act", "stats", "stats_rows", "desc", "grad", "grad_set", "need_grad", "dw", "dbias", "dgamma",
+                 "dbeta", "dx", "pad_t", "pad_l", "dgrad_descs", "wgrad_desc", "cout_pad")
+
+    def __init__(self, idx, cin, cout, k, stride, kind, src, src_up=None, shortcut=None):
+        self.idx, self.cin, self.cout, self.k, self.stride, self.kind = idx, cin, cout, k, stride, kind
+        self.src, self.src_up, self.shortcut = src, src_up, shortcut
+        for s in self.__slots__[9:]:
+            setattr(self, s, None)
+
+
+def build_topology(num_class: int, k_map: int) -> List[Layer]:
+    """The layer table of build_network (yolo/yolo3_net_pos.py:159-412, active m=1/2 mask
+    subnet).  ``src`` = producing layer (0 = the image); ``src_up`` = layer whose output is
+    nearest-upsampled x2 and concatenated AFTER ``src`` (:290-291); ``shortcut`` = layer
+    added after the activation (:148-151)."""
+    out_depth = (num_class + 5) * 3
+    Ls: List[Layer] = []
+
+    def add(idx, cin, cout, k, s, kind, src, src_up=None, shortcut=None):
+        Ls.append(Layer(idx, cin, cout, k, s, kind, src, src_up, shortcut))
+
+    add(1, 3, 32, 3, 1, "bn", 0)
+    add(2, 32, 64, 3, 2, "bn", 1)
+    i = 3
+    ch = 64
+    for nblocks, down in ((1, 5), (2, 10), (8, 27), (8, 44), (4, None)):
+        for _ in range(nblocks):
+            add(i, ch, ch // 2, 1, 1, "bn", i - 1)
+            add(i + 1, ch // 2, ch, 3, 1, "res", i, shortcut=i - 1)
+            i += 2
+        if down:
+            add(down, ch, ch * 2, 3, 2, "bn", down - 1)
+            ch *= 2
+            i = down + 1
+    # head 1
+    add(53, 1024, 512, 1, 1, "bn", 52)
+    add(54, 512, 1024, 3, 1, "bn", 53)
+    add(55, 1024, 512, 1, 1, "bn", 54)
+    add(56, 512, 1024, 3, 1, "bn", 55)
+    add(57, 1024, 512, 1, 1, "bn", 56)
+    add(58, 512, 1024, 3, 1, "bn", 57)
+    add(59, 1024, out_depth, 1, 1, "lin", 58)
+    # head 2
+    add(60, 512, 256, 1, 1, "bn", 57)
+    add(61, 768, 256, 1, 1, "bn", 43, src_up=60)
+    add(62, 256, 512, 3, 1, "bn", 61)
+    add(63, 512, 256, 1, 1, "bn", 62)
+    add(64, 256, 512, 3, 1, "bn", 63)
+    add(65, 512, 256, 1, 1, "bn", 64)
+    add(66, 256, 512, 3, 1, "bn", 65)
+    add(67, 512, out_depth, 1, 1, "lin", 66)
+    # head 3
+    add(68, 256, 128, 1, 1, "bn", 65)
+    add(69, 384, 128, 1, 1, "bn", 26, src_up=68)
+    add(70, 128, 256, 3, 1, "bn", 69)
+    add(71, 256, 128, 1, 1, "bn", 70)
+    add(72, 128, 256, 3, 1, "bn", 71)
+    add(73, 256, 128, 1, 1, "bn", 72)
+    add(74, 128, 256, 3, 1, "bn", 73)
+    add(75, 256, out_depth, 1, 1, "lin", 74)
+    # mask subnet m = 1/2
+    add(76, 128, 64, 1, 1, "bn", 73)
+    add(77, 192, 64, 1, 1, "bn", 9, src_up=76)
+    add(78, 64, 128, 3, 1, "bn", 77)
+    add(79, 128, 32, 1, 1, "bn", 78)
+    add(80, 96, 32, 1, 1, "bn", 4, src_up=79)
+    add(81, 32, 64, 3, 1, "bn", 80)
+    add(82, 64, k_map * k_map, 1, 1, "lin", 81)
+    Ls.sort(key=lambda l: l.idx)
+    # the residual shortcut of block [1x1 (i-1), 3x3 res (i)] is the block input = out(i-2)
+    for l in Ls:
+        if l.kind == "res":
+            l.shortcut = l.idx - 2
+    assert [l.idx for l in Ls] == list(range(1, 83))
+    return Ls
+
+
+def var_name(i: int, leaf: str) -> str:
+    """checkpoint variable names (train_yolo3_mask.py:86-103)"""
+    return "yolo/convolutional%d/%s" % (i, leaf)
+
+
+class YOLONet(object):
+    def __init__(self, training: bool = False, device=None, image_size: Optional[int] = None,
+                 batch_size: Optional[int] = None, stage: int = 1, lock: Optional[Dict[int, bool]] = None,
+                 seed: int = 0, xavier_locked: bool = True):
+        # 1. parameters (yolo/yolo3_net_pos.py:15-38)
+        self.batchsize = int(batch_size if batch_size is not None else cfg.BATCH_SIZE)
+        self.classes = cfg.CLASSES
+        self.num_class = len(self.classes)
+        self.anchors = np.asarray(cfg.ANCHORS, dtype=np.float32)
+        self.num_anchor = 3
+        self.output_depth = (self.num_class + 5) * self.num_anchor
+        self.k = cfg.K_MAP
+        self.k_mapout = self.k * self.k
+        self.object_scale = cfg.OBJECT_SCALE
+        self.noobject_scale = cfg.NOOBJECT_SCALE
+        self.class_scale = cfg.CLASS_SCALE
+        self.coord_scale = cfg.COORD_SCALE
+        self.mask_scale = cfg.MASK_SCALE
+        self.l2 = cfg.L2_WEIGHT
+        self.training = bool(training)
+        self.image_size = int(image_size if image_size is not None else cfg.IMAGE_SIZE)
+        if self.image_size % 32:
+            raise ValueError("image size must be a multiple of 32")
+        if device is None:
+            if not torch.cuda.is_available():
+                raise L.DisyoloError("YOLONet needs a GPU: the HIP kernels have no CPU fallback")
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        L.load()
+        self.ws = L.Workspace(self.device)
+        # lock map: stage 1 = conv1-52 locked (shipped source), stage 2 = all trainable
+        self.lock = dict(lock) if lock is not None else {i: (stage == 1 and i <= 52) for i in range(1, 83)}
+        self.layers = build_topology(self.num_class, self.k)
+        self.by_idx = {l.idx: l for l in self.layers}
+        self.step_count = 0
+        self.learning_rate = cfg.LEARNING_RATE
+        self.dp = None  # set by enable_data_parallel
+        self._init_params(seed, xavier_locked)
+        self._plan(self.batchsize, self.image_size)
+
+    # ------------------------------------------------------------------ parameters
+    def _init_params(self, seed: int, xavier_locked: bool) -> None:
+        """Variables with the reference initialisers (yolo/yolo3_net_pos.py:77-86,111-123,
+        134-140).  Trainable ones live in one flat f32 arena [weights+biases | gamma+beta] so
+        Adam and the gradient all-reduce are single contiguous sweeps."""
+        dev = self.device
+        g = torch.Generator().manual_seed(seed)
+        n_decay = 0
+        n_nodecay = 0
+        for l in self.layers:
+            l.lock = self.lock[l.idx]
+            if not l.lock:
+                n_decay += l.k * l.k * l.cin * l.cout + (l.cout if l.kind == "lin" else 0)
+                if l.kind != "lin":
+                    n_nodecay += 2 * l.cout
+        self.n_decay, self.n_params = n_decay, n_decay + n_nodecay
+        n = max(self.n_params, 1)
+        self.arena = torch.zeros(n, dtype=F32, device=dev)
+        self.grad_arena = torch.zeros(n, dtype=F32, device=dev)
+        self.adam_m = torch.zeros(n, dtype=F32, device=dev)
+        self.adam_v = torch.zeros(n, dtype=F32, device=dev)
+        self.arena_slices: Dict[str, Tuple[int, int]] = {}
+        off_d, off_n = 0, n_decay
+        self.params: Dict[str, torch.Tensor] = {}
+
+        def take(name, shape, region):
+            nonlocal off_d, off_n
+            cnt = int(np.prod(shape))
+            if region == "decay":
+                o = off_d
+                off_d += cnt
+            else:
+                o = off_n
+                off_n += cnt
+            self.arena_slices[name] = (o, cnt)
+            return self.arena[o:o + cnt].view(shape), self.grad_arena[o:o + cnt].view(shape)
+
+        for l in self.layers:
+            shape = (l.k, l.k, l.cin, l.cout)
+            if l.lock and not xavier_locked:
+                w = torch.empty(shape, dtype=torch.float64)
+                torch.nn.init.trunc_normal_(w, 0.0, 0.001, -0.002, 0.002, generator=g)
+            else:
+                lim = math.sqrt(6.0 / (l.k * l.k * l.cin + l.k * l.k * l.cout))
+                w = (torch.rand(shape, dtype=torch.float64, generator=g) * 2 - 1) * lim
+            w = w.to(F32)
+            if l.lock:
+                l.w = w.to(dev)
+            else:
+                l.w, l.dw = take(var_name(l.idx, "weights"), shape, "decay")
+                l.w.copy_(w)
+            self.params[var_name(l.idx, "weights")] = l.w
+            if l.kind == "lin":
+                if l.lock:
+                    l.bias = torch.zeros(l.cout, dtype=F32, device=dev)
+                else:
+                    l.bias, l.dbias = take(var_name(l.idx, "biases"), (l.cout,), "decay")
+                self.params[var_name(l.idx, "biases")] = l.bias
+            else:
+                if l.lock:
+                    l.gamma = torch.ones(l.cout, dtype=F32, device=dev)
+                    l.beta = torch.zeros(l.cout, dtype=F32, device=dev)
+                else:
+                    l.gamma, l.dgamma = take(var_name(l.idx, "BatchNorm/gamma"), (l.cout,), "nodecay")
+                    l.beta, l.dbeta = take(var_name(l.idx, "BatchNorm/beta"), (l.cout,), "nodecay")
+                    l.gamma.fill_(1.0)
+                l.mm = torch.zeros(l.cout, dtype=F32, device=dev)
+                l.mv = torch.ones(l.cout, dtype=F32, device=dev)
+                for leaf, t in (("gamma", l.gamma), ("beta", l.beta), ("moving_mean", l.mm),
+                                ("moving_variance", l.mv)):
+                    self.params[var_name(l.idx, "BatchNorm/" + leaf)] = t
+                l.scale = torch.empty(l.cout, dtype=F32, device=dev)
+                l.shift = torch.empty(l.cout, dtype=F32, device=dev)
+                l.mean = torch.zeros(l.cout, dtype=F32, device=dev)
+                l.rstd = torch.ones(l.cout, dtype=F32, device=dev)
+        assert off_d == n_decay and off_n == self.n_params
+
+    def trainable_names(self) -> List[str]:
+        return list(self.arena_slices)
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """Variables under the reference's checkpoint names/shapes (weights, BN gamma/beta/
+        moving stats, biases; no optimizer slots -- train_yolo3_mask.py:41-58)."""
+        return {k: v.detach().clone() for k, v in self.params.items()}
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        for k, v in sd.items():
+            if k not in self.params:
+                if strict:
+                    raise KeyError(k)
+                continue
+            self.params[k].copy_(torch.as_tensor(v).to(self.device, F32).reshape(self.params[k].shape))
+        if strict:
+            missing = set(self.params) - set(sd)
+            if missing:
+                raise KeyError("missing variables: %s" % sorted(missing)[:4])
+        self.refresh_weights()
+
+    # ------------------------------------------------------------------ static plan
+    def _plan(self, B: int, S: int) -> None:
+        """Allocate every activation / gradient buffer and build the conv descriptors once
+        for (B, S): nothing is allocated inside forward / train_step."""
+        dev = self.device
+        self.B, self.S = B, S
+        self.images = torch.zeros(B, S, S, 3, dtype=F32, device=dev)
+        spatial = {0: (S, S)}
+        # which activations need a gradient: any trainable layer at or upstream of a consumer
+        for l in self.layers:
+            H, W = spatial[l.src]
+            l.H, l.W = H, W
+            l.Ho, l.pad_t = L.same_pads(H, l.k, l.stride)
+            l.Wo, l.pad_l = L.same_pads(W, l.k, l.stride)
+            spatial[l.idx] = (l.Ho, l.Wo)
+        has_trainable_upto = {0: False}
+        for l in self.layers:
+            up = has_trainable_upto[l.src]
+            if l.src_up is not None:
+                up = up or has_trainable_upto[l.src_up]
+            if l.shortcut is not None:
+                up = up or has_trainable_upto[l.shortcut]
+            has_trainable_upto[l.idx] = up or (not l.lock)
+        self._needs_grad_into = {i: v for i, v in has_trainable_upto.items()}
+        if self.training:
+            for l in self.layers:
+                ups = [l.src] + ([l.src_up] if l.src_up is not None else [])
+                if l.lock and any(has_trainable_upto[u] for u in ups):
+                    raise NotImplementedError(
+                        "layer %d is locked but has trainable layers upstream; only the reference's two stages "
+                        "(conv1-52 locked, or nothing locked) are supported (yolo/yolo3_net_pos.py:155-156)" % l.idx)
+        for l in self.layers:
+            M = B * l.Ho * l.Wo
+            train_bn = self.training and (not l.lock) and l.kind != "lin"
+            if l.kind == "lin":
+                l.act = torch.zeros(B, l.Ho, l.Wo, l.cout, dtype=F32, device=dev)
+            else:
+                l.act = torch.zeros(B, l.Ho, l.Wo, l.cout, dtype=BF16, device=dev)
+                l.raw = torch.zeros(B, l.Ho, l.Wo, l.cout, dtype=BF16, device=dev) if train_bn else None
+            if l.idx > 1:
+                K = l.k * l.k * l.cin
+                l.wp = torch.zeros(l.cout, K, dtype=BF16, device=dev)
+            l.cout_pad = l.cout if l.cout % 32 == 0 else ((l.cout + 31) // 32) * 32
+            if self.training and not l.lock:
+                # gradient wrt this layer's conv output (bf16, row pitch cout_pad)
+                if l.kind == "lin":
+                    l.dx = torch.zeros(B, l.Ho, l.Wo, L.GRAD_LD, dtype=BF16, device=dev)
+                else:
+                    l.dx = torch.zeros(B, l.Ho, l.Wo, l.cout, dtype=BF16, device=dev)
+            if self.training and has_trainable_upto[l.idx] and l.kind != "lin":
+                l.grad = torch.zeros(B, l.Ho, l.Wo, l.cout, dtype=BF16, device=dev)
+            needs_dgrad = self.training and (not l.lock) and l.idx > 1 and (
+                has_trainable_upto[l.src] or (l.src_up is not None and has_trainable_upto[l.src_up]))
+            if needs_dgrad:
+                l.wdg = torch.zeros(l.cin, l.k * l.k * l.cout_pad, dtype=BF16, device=dev)
+        # descriptors (raw pointers into the buffers above)
+        for l in self.layers:
+            if l.idx == 1:
+                continue
+            x0 = self.by_idx[l.src].act
+            x1 = self.by_idx[l.src_up].act if l.src_up is not None else None
+            res = self.by_idx[l.shortcut].act if l.shortcut is not None else None
+            train_bn = self.training and (not l.lock) and l.kind != "lin"
+            if l.kind == "lin":
+                l.desc = L.make_conv_desc(x0, l.wp, l.act, l.k, l.stride, x1=x1, shift=l.bias, out_f32=True)
+            elif train_bn:
+                d0 = L.make_conv_desc(x0, l.wp, l.raw, l.k, l.stride, x1=x1)
+                l.stats_rows = L.conv2d_stats_rows(d0)
+                l.stats = torch.zeros(l.stats_rows, l.cout, 2, dtype=F32, device=dev)
+                l.desc = L.make_conv_desc(x0, l.wp, l.raw, l.k, l.stride, x1=x1, stats=l.stats)
+            else:
+                l.desc = L.make_conv_desc(x0, l.wp, l.act, l.k, l.stride, x1=x1, scale=l.scale, shift=l.shift,
+                                          residual=res, leaky=True, alpha=cfg.ALPHA)
+            if self.training and not l.lock:
+                l.wgrad_desc = L.make_conv_desc(x0, l.wp, l.act, l.k, l.stride, x1=x1)
+        l1 = self.by_idx[1]
+        if self.training and not l1.lock:
+            l1.stats_rows = L.colstats_rows(B * S * S, l1.cout)
+            l1.stats = torch.zeros(l1.stats_rows, l1.cout, 2, dtype=F32, device=dev)
+            self._ones32 = torch.ones(l1.cout, dtype=F32, device=dev)
+            self._zeros32 = torch.zeros(l1.cout, dtype=F32, device=dev)
+        # detection / loss buffers
+        self.clip_window = torch.zeros(B, 4, dtype=F32, device=dev)
+        self.detections = torch.zeros(B, cfg.MAX_DETECTION, 6, dtype=F32, device=dev)
+        self.det_count = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.masks = None
+        self.keep = torch.zeros(B, cfg.MAX_DETECTION, dtype=torch.int32, device=dev)
+        if self.training:
+            G = cfg.MAX_BOX_PER_IMAGE
+            g1 = S // 32
+            self.labels = [torch.zeros(B, g, g, 3, 5 + self.num_class, dtype=F32, device=dev)
+                           for g in (4 * g1, 2 * g1, g1)]          # yolo3, yolo2, yolo1
+            self.true_boxes = torch.zeros(B, G, 5, dtype=F32, device=dev)
+            self.true_masks = torch.zeros(B, G, S, S, dtype=torch.uint8, device=dev)
+            self.perm_det = torch.arange(cfg.MAX_DETECTION, dtype=torch.int32, device=dev).repeat(B, 1).contiguous()
+            self.perm_gt = torch.arange(G, dtype=torch.int32, device=dev).repeat(B, 1).contiguous()
+            self.rois = torch.zeros(B, L.ROI_MAX, L.ROI_W, dtype=torch.int32, device=dev)
+            self.roi_count = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.losses = torch.zeros(8, dtype=F32, device=dev)
+            self.mask_loss = torch.zeros(1, dtype=F32, device=dev)
+            self.reg_loss = torch.zeros(1, dtype=F32, device=dev)
+            # temp for the data gradient of the fused upsample+concat layers (full-res, C1 ch)
+            tmax = 0
+            for l in self.layers:
+                if l.src_up is not None and l.wdg is not None:
+                    tmax = max(tmax, B * l.H * l.W * self.by_idx[l.src_up].cout)
+            self.up_tmp = torch.zeros(max(tmax, 1), dtype=BF16, device=dev)
+            # size the shared workspace once (wgrad slabs dominate)
+            need = 1 << 20
+            for l in self.layers:
+                if l.wgrad_desc is not None:
+                    import ctypes
+                    need = max(need, L.load().disyolo_conv2d_wgrad_workspace(ctypes.byref(l.wgrad_desc)))
+                if l.dx is not None and l.kind != "lin":
+                    need = max(need, L.load().disyolo_bn_act_bwd_workspace(B * l.Ho * l.Wo, l.cout))
+            need = max(need, L.load().disyolo_conv_first_wgrad_workspace(B, S, S, 32))
+            self.ws.get(int(need))
+        self.ws.get(int(max(L.load().disyolo_detect_workspace(B, S, self.num_class), 1 << 20)))
+        self._build_dgrad_descs()
+        self.refresh_weights()
+
+    def _build_dgrad_descs(self) -> None:
+        """Data-gradient convs: forward kernel over dx with the flipped operand (wdg), pads
+        k-1-pad and the transposed gather (in_div = stride)."""
+        for l in self.layers:
+            l.dgrad_descs = []
+            if l.wdg is None:
+                continue
+            Kp = l.k * l.k * l.cout_pad
+            pads = (l.k - 1 - l.pad_t, l.k - 1 - l.pad_l)
+            if l.src_up is None:
+                tgt = self.by_idx[l.src]
+                l.dgrad_descs.append(("direct", tgt, dict(w=l.wdg, pads=pads, out_hw=(l.H, l.W))))
+            else:
+                skip, up = self.by_idx[l.src], self.by_idx[l.src_up]
+                if self._needs_grad_into[skip.idx]:
+                    l.dgrad_descs.append(("direct", skip, dict(w=l.wdg[:skip.cout], pads=pads, out_hw=(l.H, l.W))))
+                if self._needs_grad_into[up.idx]:
+                    tmp = self.up_tmp[:self.B * l.H * l.W * up.cout].view(self.B, l.H, l.W, up.cout)
+                    l.dgrad_descs.append(("up", up, dict(w=l.wdg[skip.cout:skip.cout + up.cout], pads=pads,
+                                                         out_hw=(l.H, l.W), tmp=tmp)))
+
+    def refresh_weights(self) -> None:
+        """(Re)pack the bf16 MFMA operands from the f32 masters and fold the locked /
+        inference batch-norm statistics into per-channel scale/shift."""
+        for l in self.layers:
+            if l.idx > 1:
+                L.pack_weights(l.w, l.wp, l.wdg, l.k, l.cin, l.cout, l.cout_pad)
+            if l.kind != "lin":
+                L.bn_fold(l.gamma, l.beta, l.mm, l.mv, cfg.BN_EPSILON, l.scale, l.shift)
+
+    # ------------------------------------------------------------------ forward
+    def _forward_layers(self, is_training: bool) -> None:
+        B = self.B
+        for l in self.layers:
+            train_bn = is_training and self.training and (not l.lock) and l.kind != "lin"
+            M = B * l.Ho * l.Wo
+            res = self.by_idx[l.shortcut].act if l.shortcut is not None else None
+            if l.idx == 1:
+                if train_bn:
+                    L.conv_first_fwd(self.images, l.w, self._ones32, self._zeros32, l.raw, alpha=1.0)
+                    L.colstats(l.raw, l.stats, M, l.cout)
+                    L.bn_finalize(l.stats, l.stats_rows, l.cout, M, l.gamma, l.beta, l.mm, l.mv, cfg.BN_DECAY,
+                                  cfg.BN_EPSILON, l.scale, l.shift, l.mean, l.rstd)
+                    L.bn_act_fwd(l.raw, l.scale, l.shift, None, l.act, M, l.cout, cfg.ALPHA)
+                else:
+                    if not l.lock and self.training:
+                        L.bn_fold(l.gamma, l.beta, l.mm, l.mv, cfg.BN_EPSILON, l.scale, l.shift)
+                    L.conv_first_fwd(self.images, l.w, l.scale, l.shift, l.act, alpha=cfg.ALPHA)
+                continue
+            if l.kind == "lin":
+                L.conv2d_fwd(l.desc)
+            elif train_bn:
+                L.conv2d_fwd(l.desc)                       # raw conv + per-channel partial sums
+                L.bn_finalize(l.stats, l.stats_rows, l.cout, M, l.gamma, l.beta, l.mm, l.mv, cfg.BN_DECAY,
+                              cfg.BN_EPSILON, l.scale, l.shift, l.mean, l.rstd)
+                L.bn_act_fwd(l.raw, l.scale, l.shift, res, l.act, M, l.cout, cfg.ALPHA)
+            else:
+                if self.training and not l.lock:
+                    # a training-mode plan evaluated with is_training=False: moving statistics
+                    L.bn_fold(l.gamma, l.beta, l.mm, l.mv, cfg.BN_EPSILON, l.scale, l.shift)
+                    d = L.make_conv_desc(self.by_idx[l.src].act, l.wp, l.act, l.k, l.stride,
+                                         x1=self.by_idx[l.src_up].act if l.src_up is not None else None,
+                                         scale=l.scale, shift=l.shift, residual=res, leaky=True, alpha=cfg.ALPHA)
+                    L.conv2d_fwd(d)
+                else:
+                    L.conv2d_fwd(l.desc)
+
+    def _detect(self, det_thresh: float) -> None:
+        L.detect(self.by_idx[75].act, self.by_idx[67].act, self.by_idx[59].act, self.B, self.S, self.num_class,
+                 self.anchors.reshape(-1), self.clip_window, float(det_thresh), cfg.IOU_THRESHOLD, cfg.MAX_DETECTION,
+                 self.detections, self.det_count, self.ws)
+
+    def _set_inputs(self, images, clip_window) -> None:
+        images = torch.as_tensor(images)
+        if tuple(images.shape) != (self.B, self.S, self.S, 3):
+            raise ValueError("images must be [%d,%d,%d,3] NHWC (batch size and image size are baked into the plan, "
+                             "as in the reference: yolo/yolo3_net_pos.py:17)" % (self.B, self.S, self.S))
+        self.images.copy_(images.to(self.device, F32, non_blocking=True))
+        self.clip_window.copy_(torch.as_tensor(clip_window).to(self.device, F32).reshape(self.B, 4))
+
+    def forward(self, images, clip_window, det_thresh=cfg.OBJ_THRESHOLD, is_training: bool = False):
+        """``sess.run(net.logits)``: returns (predictions, detections, mask_pos) with
+        predictions = [yolov3_3, yolov3_2, yolov3_1] raw logits [B,g,g,3,5+C] (f32),
+        detections [B,30,6], mask_pos [B,S/2,S/2,k*k] (yolo/yolo3_net_pos.py:353-357,463)."""
+        self._set_inputs(images, clip_window)
+        self._forward_layers(is_training)
+        self._detect(float(np.asarray(det_thresh).reshape(-1)[0]))
+        preds = [self.by_idx[i].act.view(self.B, self.by_idx[i].Ho, self.by_idx[i].Wo, 3, 5 + self.num_class)
+                 for i in (75, 67, 59)]
+        return preds, self.detections, self.by_idx[82].act
+
+    def evaluation(self, images, clip_window, det_thresh=cfg.OBJ_THRESHOLD):
+        """``sess.run(net.evaluation)`` (val_test, yolo/yolo3_net_pos.py:862-938): returns
+        [det_box, det_mask]: per image an [n,6] array and an [n,S/2,S/2] array (scalar 0.0
+        when the image has no valid detection, :933)."""
+        self.forward(images, clip_window, det_thresh, is_training=False)
+        Sm = self.S // 2
+        if self.masks is None:
+            self.masks = torch.zeros(self.B, cfg.MAX_DETECTION, Sm, Sm, dtype=F32, device=self.device)
+        L.psroi_assemble(self.by_idx[82].act, self.detections, self.B, cfg.MAX_DETECTION, Sm, self.k, self.masks,
+                         self.keep)
+        keep = self.keep.cpu().numpy().astype(bool)
+        det = self.detections.cpu().numpy()
+        det_box, det_mask = [], []
+        for b in range(self.B):
+            det_box.append(det[b][keep[b]])
+            if keep[b].any():
+                det_mask.append(self.masks[b][torch.from_numpy(keep[b]).to(self.device)].cpu().numpy())
+            else:
+                det_mask.append(np.float32(0.0))
+        return [det_box, det_mask]
+
+    # ------------------------------------------------------------------ training
+    def set_batch(self, batch: Dict) -> None:
+        """feed_dict of Solver.train (train_yolo3_mask.py:146-149)."""
+        self._set_inputs(batch["images"], batch["clip_window"])
+        dev = self.device
+        for t, key in zip(self.labels, ("yolo3", "yolo2", "yolo1")):
+            t.copy_(torch.as_tensor(batch[key]).to(dev, F32).reshape(t.shape))
+        self.true_boxes.copy_(torch.as_tensor(batch["true_boxes"]).to(dev, F32).reshape(self.true_boxes.shape))
+        tm = torch.as_tensor(batch["true_masks"])
+        self.true_masks.copy_(tm.to(dev).to(torch.uint8).reshape(self.true_masks.shape))
+        if batch.get("perm_det") is not None:
+            self.perm_det.copy_(torch.as_tensor(batch["perm_det"]).to(dev, torch.int32).reshape(self.perm_det.shape))
+            self.perm_gt.copy_(torch.as_tensor(batch["perm_gt"]).to(dev, torch.int32).reshape(self.perm_gt.shape))
+
+    def shuffle_rois(self, generator: Optional[torch.Generator] = None) -> None:
+        """tf.random_shuffle of proposals / GT boxes (yolo/yolo3_net_pos.py:781-782)."""
+        B = self.B
+        self.perm_det.copy_(torch.rand(B, cfg.MAX_DETECTION, device=self.device, generator=generator).argsort(dim=1))
+        self.perm_gt.copy_(torch.rand(B, cfg.MAX_BOX_PER_IMAGE, device=self.device, generator=generator).argsort(dim=1))
+
+    def compute_losses(self, det_thresh: float = cfg.OBJ_THRESHOLD) -> None:
+        """forward (training mode) + detections + both losses and their gradients wrt the
+        head logits / score maps (yolo/yolo3_net_pos.py:59-60)."""
+        self._forward_layers(True)
+        self._detect(det_thresh)
+        heads = [self.by_idx[75], self.by_idx[67], self.by_idx[59]]
+        L.yolo_loss([h.act for h in heads], self.labels, self.true_boxes, cfg.MAX_BOX_PER_IMAGE, self.B, self.S,
+                    self.num_class, self.anchors.reshape(-1), cfg.IGNORE_THRESH,
+                    (self.object_scale, self.noobject_scale, self.class_scale, self.coord_scale),
+                    [h.dx for h in heads], self.losses, self.ws)
+        Sm = self.S // 2
+        L.mask_rois(self.detections, cfg.MAX_DETECTION, self.true_boxes, cfg.MAX_BOX_PER_IMAGE, self.perm_det,
+                    self.perm_gt, self.B, Sm, cfg.MASK_ROI_DET, cfg.MASK_ROI_GT, cfg.MASK_ROI_IOU, self.rois,
+                    self.roi_count)
+        m = self.by_idx[82]
+        L.psroi_loss(m.act, self.true_masks, cfg.MAX_BOX_PER_IMAGE, self.rois, self.roi_count, self.B, Sm, self.k,
+                     self.mask_scale, m.dx, self.mask_loss, self.ws)
+
+    def _accumulate_into(self, tgt: Layer, desc_kw: dict, dx: torch.Tensor, cin_eff: int, k: int, in_div: int) -> None:
+        """one data-gradient conv writing (first contribution) or accumulating into tgt.grad"""
+        out = desc_kw.get("tmp", tgt.grad)
+        first = not tgt.grad_set
+        d = L.make_conv_desc(dx, desc_kw["w"], out, k, 1, in_div=in_div, pads=desc_kw["pads"], out_hw=desc_kw["out_hw"],
+                             residual=None if (first or "tmp" in desc_kw) else tgt.grad)
+        L.conv2d_fwd(d)
+
+    def backward(self, on_layer_done=None) -> None:
+        """TF autodiff of total_loss restated layer by layer in reverse order.  Gradients of
+        the trainable variables land in ``grad_arena``.  ``on_layer_done(layer)`` is called
+        after a layer's parameter gradients are enqueued (used to overlap the RCCL
+        all-reduce with the rest of the backward pass)."""
+        B = self.B
+        for l in self.layers:
+            l.grad_set = False
+        for l in reversed(self.layers):
+            if l.lock:
+                # locked layers still pass gradients through their residual add only in
+                # stage 2; in stage 1 nothing upstream is trainable
+                continue
+            M = B * l.Ho * l.Wo
+            if l.kind == "lin":
+                L.colsum(l.dx, l.dbias, M, L.GRAD_LD, l.cout, self.ws)
+                dx, ld = l.dx, L.GRAD_LD
+            else:
+                if not l.grad_set:
+                    raise L.DisyoloError("layer %d received no gradient" % l.idx)
+                L.bn_act_bwd(l.grad, l.raw, l.scale, l.shift, l.mean, l.rstd, l.dx, l.dgamma, l.dbeta, M, l.cout,
+                             self.ws, cfg.ALPHA)
+                dx, ld = l.dx, l.cout
+                if l.shortcut is not None:
+                    sc = self.by_idx[l.shortcut]
+                    if sc.grad is not None:
+                        if sc.grad_set:
+                            sc.grad.add_(l.grad)
+                        else:
+                            sc.grad.copy_(l.grad)
+                            sc.grad_set = True
+            if l.idx == 1:
+                L.conv_first_wgrad(self.images, l.dx, l.dw, self.ws)
+            else:
+                L.conv2d_wgrad(l.wgrad_desc, dx, ld, l.dw, self.ws)
+            for mode, tgt, kw in l.dgrad_descs:
+                if mode == "direct":
+                    self._accumulate_into(tgt, kw, dx, l.cin, l.k, l.stride)
+                    tgt.grad_set = True
+                else:
+                    self._accumulate_into(tgt, kw, dx, l.cin, l.k, l.stride)
+                    up = tgt
+                    L.upsample2x_bwd(kw["tmp"], up.grad, B, l.H, l.W, up.cout, 0, up.cout, accumulate=up.grad_set)
+                    up.grad_set = True
+            if on_layer_done is not None:
+                on_layer_done(l)
+
+    def optimizer_step(self, grad_scale: float = 1.0) -> None:
+        """tf.train.AdamOptimizer(1e-4).minimize (train_yolo3_mask.py:55) over the arena; the
+        l2 regulariser's gradient (l2*w) is folded in for weights and biases."""
+        self.step_count += 1
+        if self.n_params:
+            L.adam_step(self.arena, self.grad_arena, self.adam_m, self.adam_v, self.n_params, self.n_decay,
+                        self.learning_rate, cfg.ADAM_BETA1, cfg.ADAM_BETA2, cfg.ADAM_EPSILON, self.l2,
+                        self.step_count, grad_scale)
+        for l in self.layers:
+            if not l.lock and l.idx > 1:
+                L.pack_weights(l.w, l.wp, l.wdg, l.k, l.cin, l.cout, l.cout_pad)
+
+    def total_loss(self) -> torch.Tensor:
+        """conf + class + coord + mask + l2 term as a device scalar (tf.losses.get_total_loss,
+        yolo/yolo3_net_pos.py:61).  Valid after compute_losses()."""
+        if self.n_decay:
+            L.l2_loss(self.arena, self.n_decay, self.l2, self.reg_loss, self.ws)
+        return self.losses[7] + self.mask_loss[0] + self.reg_loss[0]
+
+    def train_step(self, batch: Optional[Dict] = None, det_thresh: float = cfg.OBJ_THRESHOLD,
+                   want_loss: bool = True):
+        """``sess.run([net.total_loss, optimizer], feed_dict)`` (train_yolo3_mask.py:216)."""
+        if not self.training:
+            raise L.DisyoloError("train_step on a YOLONet built with training=False")
+        if batch is not None:
+            self.set_batch(batch)
+        self.compute_losses(det_thresh)
+        loss = self.total_loss() if want_loss else None   # loss of the pre-update weights, like TF
+        if self.dp is not None:
+            self.dp.begin_step()
+            self.backward(self.dp.on_layer_done)
+            self.dp.finish()
+            self.optimizer_step(1.0 / self.dp.world_size)
+        else:
+            self.backward()
+            self.optimizer_step()
+        return loss
+
+    def summaries(self) -> Dict[str, float]:
+        """the 7 tf.summary scalars (yolo/yolo3_net_pos.py:62,743-747,860)."""
+        v = self.losses.cpu().numpy()
+        ml = float(self.mask_loss.cpu()[0])
+        return {"object_loss": float(v[0]), "noobject_loss": float(v[1]), "class_loss": float(v[2]),
+                "xy_loss": float(v[3]), "wh_loss": float(v[4]), "mask_loss": ml,
+                "total_loss": float(self.total_loss().cpu())}

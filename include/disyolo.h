@@ -109,6 +109,10 @@ int disyolo_bn_finalize(const float* stats, int rows, int C, int64_t count, cons
                         const float* beta, float* moving_mean, float* moving_var, float decay,
                         float eps, float* scale, float* shift, float* mean, float* rstd,
                         void* stream);
+/* (sum, sum of squares) partials of a materialised bf16 [rows,C] conv output, in the layout
+ * bn_finalize consumes: stats f32 [disyolo_colstats_rows(rows,C)][C][2] */
+int disyolo_colstats_rows(int64_t rows, int C);
+int disyolo_colstats(const void* x, float* stats, int64_t rows, int C, void* stream);
 /* locked / inference BN folded to scale/shift from the moving statistics (:81,:101) */
 int disyolo_bn_fold(const float* gamma, const float* beta, const float* moving_mean,
                     const float* moving_var, float eps, float* scale, float* shift, int C,

@@ -198,8 +198,21 @@ def conv2d_same(x: torch.Tensor, w_hwio: torch.Tensor, stride: int) -> torch.Ten
     return y.permute(0, 2, 3, 1)
 
 
+def bf16_ste(t: torch.Tensor) -> torch.Tensor:
+    """Round to bf16 (nearest-even) with a straight-through gradient.  NOT part of the
+    reference (which is f32 throughout): passing ``quant=bf16_ste`` to build_network makes
+    the oracle round weights and stored activations exactly where the bf16 HIP path does,
+    so parity tests can use tolerances of a few bf16 ulps instead of the accumulated
+    mixed-precision drift of 75 layers."""
+    return t + (t.detach().to(torch.bfloat16).to(t.dtype) - t.detach())
+
+
+def _q(quant, t):
+    return t if quant is None else quant(t)
+
+
 def batch_norm(x: torch.Tensor, params: Dict[str, torch.Tensor], i: int, lock: bool,
-               is_training: bool, updates: Optional[Dict[str, torch.Tensor]]) -> torch.Tensor:
+               is_training: bool, updates: Optional[Dict[str, torch.Tensor]], quant=None) -> torch.Tensor:
     """yolo/yolo3_net_pos.py:71-107.
 
     lock: moving stats always (:76-81).  Otherwise training: batch moments over
@@ -220,19 +233,24 @@ def batch_norm(x: torch.Tensor, params: Dict[str, torch.Tensor], i: int, lock: b
             updates[_name(i, "BatchNorm/moving_mean")] = (mm * BN_DECAY + mean.detach() * (1 - BN_DECAY))
             updates[_name(i, "BatchNorm/moving_variance")] = (mv * BN_DECAY + var.detach() * (1 - BN_DECAY))
     # tf.nn.batch_normalization: (x-mean)*rsqrt(var+eps)*gamma + beta
+    # (with ``quant`` the statistics come from the unrounded conv output and the
+    #  normalisation reads the stored, rounded copy -- what the two-pass HIP path does)
+    if quant is not None and not (lock or not is_training):
+        x = quant(x)
     return (x - mean) * torch.rsqrt(var + BN_EPS) * gamma + beta
 
 
-def conv_bn(x, params, i, stride, lock, is_training, updates, alpha=ALPHA):
+def conv_bn(x, params, i, stride, lock, is_training, updates, alpha=ALPHA, quant=None):
     """yolo/yolo3_net_pos.py:132-146."""
-    y = conv2d_same(x, params[_name(i, "weights")], stride)
-    y = batch_norm(y, params, i, lock, is_training, updates)
+    w = params[_name(i, "weights")]
+    y = conv2d_same(x, w if i == 1 else _q(quant, w), stride)
+    y = batch_norm(y, params, i, lock, is_training, updates, quant)
     return leaky_relu(y, alpha)
 
 
-def conv_lin(x, params, i):
+def conv_lin(x, params, i, quant=None):
     """yolo/yolo3_net_pos.py:109-130 with is_bias=True, is_act=False (all 4 call sites)."""
-    return conv2d_same(x, params[_name(i, "weights")], 1) + params[_name(i, "biases")]
+    return conv2d_same(x, _q(quant, params[_name(i, "weights")]), 1) + params[_name(i, "biases")]
 
 
 def upsample2(x: torch.Tensor) -> torch.Tensor:
@@ -243,22 +261,34 @@ def upsample2(x: torch.Tensor) -> torch.Tensor:
 
 def build_network(params: Dict[str, torch.Tensor], images: torch.Tensor, is_training: bool,
                   lock: Dict[int, bool], updates: Optional[Dict[str, torch.Tensor]] = None,
-                  taps: Optional[Dict[str, torch.Tensor]] = None):
+                  taps: Optional[Dict[str, torch.Tensor]] = None, quant=None,
+                  force: Optional[Dict[str, torch.Tensor]] = None):
     """yolo/yolo3_net_pos.py:153-463 (the active m=1/2 mask subnet, :380-412).
 
     Returns (yolos=[yolov3_3, yolov3_2, yolov3_1] each [B,g,g,3,5+C], mask_pos
     [B,S/2,S/2,k*k]).  ``taps`` (optional) collects intermediate activations by
-    name ('act{i}') for per-layer parity tests.
+    name ('act{i}') for per-layer parity tests.  ``force`` (optional, test aid) replaces
+    the VALUE of the named activations after they are recorded in ``taps`` while keeping
+    the autograd path (straight-through): each layer is then evaluated -- and later
+    differentiated -- at the caller's linearisation point, so a per-layer comparison is not
+    swamped by the chaotic amplification of bf16 rounding through 30 batch-stat BN layers
+    of a randomly initialised network.
     """
     sp = layer_specs()
 
     def cb(x, i):
-        y = conv_bn(x, params, i, sp[i][3], lock[i], is_training, updates)
+        y = conv_bn(x, params, i, sp[i][3], lock[i], is_training, updates, quant=quant)
         return y
 
     def tap(name, t):
+        # every stored activation is rounded once, after the residual add (bf16 path);
+        # head logits / score maps stay f32
+        if quant is not None and name not in ("act59", "act67", "act75", "act82"):
+            t = quant(t)
         if taps is not None:
             taps[name] = t
+        if force is not None and name in force:
+            t = t + (force[name].to(t.dtype) - t).detach()
         return t
 
     net = tap("act1", cb(images, 1))                                     # :159
@@ -280,7 +310,7 @@ def build_network(params: Dict[str, torch.Tensor], images: torch.Tensor, is_trai
     for i in (53, 54, 55, 56, 57):
         net = tap("act%d" % i, cb(net, i))
     y1 = tap("act58", cb(net, 58))
-    y1 = tap("act59", conv_lin(y1, params, 59))
+    y1 = tap("act59", conv_lin(y1, params, 59, quant))
     B = images.shape[0]
     yolov3_1 = y1.reshape(B, y1.shape[1], y1.shape[2], NUM_ANCHOR, -1)
     # head 2 (:285-316)
@@ -289,7 +319,7 @@ def build_network(params: Dict[str, torch.Tensor], images: torch.Tensor, is_trai
     for i in (61, 62, 63, 64, 65):
         net = tap("act%d" % i, cb(net, i))
     y2 = tap("act66", cb(net, 66))
-    y2 = tap("act67", conv_lin(y2, params, 67))
+    y2 = tap("act67", conv_lin(y2, params, 67, quant))
     yolov3_2 = y2.reshape(B, y2.shape[1], y2.shape[2], NUM_ANCHOR, -1)
     # head 3 (:320-351)
     net = tap("act68", cb(net, 68))
@@ -297,7 +327,7 @@ def build_network(params: Dict[str, torch.Tensor], images: torch.Tensor, is_trai
     for i in (69, 70, 71, 72, 73):
         net = tap("act%d" % i, cb(net, i))
     y3 = tap("act74", cb(net, 74))
-    y3 = tap("act75", conv_lin(y3, params, 75))
+    y3 = tap("act75", conv_lin(y3, params, 75, quant))
     yolov3_3 = y3.reshape(B, y3.shape[1], y3.shape[2], NUM_ANCHOR, -1)
     # mask subnet m=1/2 (:381-412), branches from conv73's output
     net = tap("act76", cb(net, 76))
@@ -308,7 +338,7 @@ def build_network(params: Dict[str, torch.Tensor], images: torch.Tensor, is_trai
     net = torch.cat([skips["skip2"], upsample2(net)], dim=-1)            # :401-402
     net = tap("act80", cb(net, 80))
     net = tap("act81", cb(net, 81))
-    mask_pos = tap("act82", conv_lin(net, params, 82))                   # :410
+    mask_pos = tap("act82", conv_lin(net, params, 82, quant))                   # :410
     return [yolov3_3, yolov3_2, yolov3_1], mask_pos
 
 
@@ -403,9 +433,9 @@ def filter_detections(conf_logit, class_logit, pred_norm_coord, batch_window, ob
     for i in range(B):
         confs, clss, boxes = [], [], []
         for j in (0, 1, 2):                                             # :527-538 order 72,36,18
-            confs.append(torch.sigmoid(conf_logit[j][i].float()).reshape(-1))
-            clss.append(torch.softmax(class_logit[j][i].float(), dim=-1).reshape(-1, class_logit[j].shape[-1]))
-            boxes.append(pred_norm_coord[j][i].float().reshape(-1, 4))
+            confs.append(torch.sigmoid(conf_logit[j][i].detach().float()).reshape(-1))
+            clss.append(torch.softmax(class_logit[j][i].detach().float(), dim=-1).reshape(-1, class_logit[j].shape[-1]))
+            boxes.append(pred_norm_coord[j][i].detach().float().reshape(-1, 4))
         pred_conf = torch.cat(confs).numpy()
         pred_class = torch.cat(clss).numpy()
         box = torch.cat(boxes).numpy()
@@ -635,10 +665,11 @@ def l2_regularization(params: Dict[str, torch.Tensor], lock: Dict[int, bool]) ->
     return tot
 
 
-def total_loss(params, batch, lock, is_training=True, perms=None, updates=None, obj_thresh=OBJ_THRESHOLD):
+def total_loss(params, batch, lock, is_training=True, perms=None, updates=None, obj_thresh=OBJ_THRESHOLD,
+               quant=None, taps=None, force=None):
     """YOLONet.__init__ wiring, yolo/yolo3_net_pos.py:47-61.  ``batch`` keys: images,
     clip_window, true_boxes, true_masks, yolo1, yolo2, yolo3 (torch / numpy)."""
-    yolos, mask_pos = build_network(params, batch["images"], is_training, lock, updates)
+    yolos, mask_pos = build_network(params, batch["images"], is_training, lock, updates, taps, quant, force)
     pred = interpret_output(yolos)
     with torch.no_grad():
         det = filter_detections(pred[2], pred[3], pred[5], batch["clip_window"], obj_thresh)

@@ -1,0 +1,226 @@
+"""GPU parity of the whole hot path (network, detection filter, losses, backward, Adam)
+against the CPU oracle, on small configurations the oracle finishes in seconds.
+
+Two oracle modes are used:
+  * ``quant=bf16_ste``: the oracle rounds weights / stored activations to bf16 at the same
+    points as the HIP path, so the remaining differences are f32 accumulation order and
+    bf16 rounding-boundary flips -> tolerances of a few bf16 ulps (2^-8 relative);
+  * plain f32 (the reference's arithmetic): loose end-to-end tolerance, stated per test.
+"""
+import numpy as np
+import pytest
+import torch
+
+import disyolo_oracle as O
+from disyolo_amd import lib as L
+from disyolo_amd.net import YOLONet
+from disyolo_amd import config as cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(got, want):
+    got = torch.as_tensor(got).double().cpu().flatten()
+    want = torch.as_tensor(want).detach().double().cpu().flatten()
+    return float((got - want).norm() / (want.norm() + 1e-30)), float((got - want).abs().max()), float(want.abs().max())
+
+
+def make_net(dev, training, stage, B=2, S=64, seed=0):
+    net = YOLONet(training=training, device=dev, image_size=S, batch_size=B, stage=stage, seed=seed)
+    # make the heads produce non-trivial logits / detections
+    with torch.no_grad():
+        for i in (59, 67, 75, 82):
+            net.params["yolo/convolutional%d/weights" % i].mul_(6.0)
+            net.params["yolo/convolutional%d/biases" % i].normal_(0, 0.5)
+    net.refresh_weights()
+    return net
+
+
+def oracle_params(net, dtype=torch.float32):
+    return {k: v.detach().cpu().to(dtype).clone() for k, v in net.params.items()}
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+def test_inference_forward_matches_oracle(dev, stage):
+    net = make_net(dev, False, stage)
+    b = O.synthetic_batch(2, 64, seed=3)
+    preds, det, mask_pos = net.forward(b["images"], b["clip_window"], [0.1], is_training=False)
+    torch.cuda.synchronize()
+    p = oracle_params(net)
+    lock = O.default_lock(stage)
+    yq, mq = O.build_network(p, b["images"], False, lock, quant=O.bf16_ste)
+    yf, mf = O.build_network(p, b["images"], False, lock)
+    for got, wq, wf in list(zip(preds, yq, yf)) + [(mask_pos, mq, mf)]:
+        r, _, _ = rel_err(got, wq)
+        assert r < 2e-2, "vs bf16-emulating oracle: rel l2 err %.3g" % r
+        r, _, _ = rel_err(got, wf)
+        assert r < 8e-2, "vs f32 oracle (reference arithmetic): rel l2 err %.3g" % r
+
+
+def test_detect_matches_oracle_on_same_logits(dev):
+    net = make_net(dev, False, 1, B=2, S=96)
+    b = O.synthetic_batch(2, 96, seed=5)
+    b["clip_window"][1] = [0.1, 0.05, 0.9, 0.8]
+    preds, det, _ = net.forward(b["images"], b["clip_window"], [0.05], is_training=False)
+    torch.cuda.synchronize()
+    yolos = [t.cpu() for t in preds]
+    pred = O.interpret_output(yolos)
+    want = O.filter_detections(pred[2], pred[3], pred[5], b["clip_window"], 0.05)
+    got = det.cpu().numpy()
+    assert (want[:, :, 5] > 0).sum() >= 20, "test needs a non-trivial number of detections"
+    np.testing.assert_array_equal(got[:, :, 4], want[:, :, 4])
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    assert net.det_count.cpu().tolist() == [(want[i, :, 5] > 0).sum() for i in range(2)]
+
+
+def test_evaluation_matches_oracle_val_test(dev):
+    net = make_net(dev, False, 1, B=2, S=96)
+    b = O.synthetic_batch(2, 96, seed=6)
+    det_box, det_mask = net.evaluation(b["images"], b["clip_window"], [0.05])
+    torch.cuda.synchronize()
+    wb, wm = O.val_test(net.detections.cpu().numpy(), net.by_idx[82].act.cpu())
+    for i in range(2):
+        np.testing.assert_array_equal(det_box[i], wb[i])
+        np.testing.assert_allclose(det_mask[i], wm[i], rtol=1e-5, atol=1e-6)
+        if np.ndim(wm[i]):
+            # outside the box the assembled mask is sigmoid(0) = 0.5 (yolo/yolo3_net_pos.py:927)
+            assert (wm[i] == 0.5).any()
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+def test_train_step_matches_oracle(dev, stage):
+    B, S = 2, 64
+    net = make_net(dev, True, stage, B=B, S=S, seed=1)
+    b = O.synthetic_batch(B, S, seed=11)
+    rng = np.random.RandomState(0)
+    perm_det = np.stack([rng.permutation(cfg.MAX_DETECTION) for _ in range(B)]).astype(np.int32)
+    perm_gt = np.stack([rng.permutation(cfg.MAX_BOX_PER_IMAGE) for _ in range(B)]).astype(np.int32)
+    b["perm_det"], b["perm_gt"] = perm_det, perm_gt
+    p0 = oracle_params(net)
+    lock = O.default_lock(stage)
+    net.set_batch(b)
+    net.compute_losses(0.1)
+    torch.cuda.synchronize()
+    # ---- loss kernels vs oracle on the SAME logits / score maps / detections ----
+    yolos = [net.by_idx[i].act.cpu().view(B, net.by_idx[i].Ho, net.by_idx[i].Wo, 3, 8).clone().requires_grad_(True)
+             for i in (75, 67, 59)]
+    pred = O.interpret_output(yolos)
+    ly = O.loss_yolo(pred, b["true_boxes"], [b["yolo3"], b["yolo2"], b["yolo1"]])
+    (ly["conf"] + ly["class"] + ly["coord"]).backward()
+    got = net.losses.cpu().numpy()
+    want = [float(ly[k]) for k in ("obj", "noobj", "class", "xy", "wh")]
+    np.testing.assert_allclose(got[:5], want, rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(got[7], sum(want), rtol=2e-4)
+    for i, y in zip((75, 67, 59), yolos):
+        dl = net.by_idx[i].dx.float().cpu()
+        assert float(dl[..., 24:].abs().max()) == 0.0
+        r, _, _ = rel_err(dl[..., :24].reshape(y.shape), y.grad)
+        assert r < 6e-3, "dlogits of head %d: rel err %.3g (bf16 rounding only)" % (i, r)
+    det = net.detections.cpu().numpy()
+    want_det = O.filter_detections(pred[2], pred[3], pred[5], b["clip_window"], 0.1)
+    np.testing.assert_allclose(det, want_det, rtol=1e-5, atol=1e-6)
+    mp = net.by_idx[82].act.cpu().clone().requires_grad_(True)
+    perms = [(perm_det[i], perm_gt[i]) for i in range(B)]
+    lm = O.loss_mask(det, mp, b["true_boxes"].numpy(), b["true_masks"], perms)
+    assert int(net.roi_count.sum()) > 0, "test needs at least one positive RoI"
+    lm.backward()
+    np.testing.assert_allclose(float(net.mask_loss.cpu()[0]), float(lm), rtol=2e-4)
+    ds = net.by_idx[82].dx.float().cpu()
+    assert float(ds[..., 9:].abs().max()) == 0.0
+    r, _, _ = rel_err(ds[..., :9], mp.grad)
+    assert r < 6e-3, "dscore rel err %.3g" % r
+
+    # ---- whole step vs the bf16-emulating oracle, evaluated layer by layer at the HIP
+    # path's own activations (build_network(force=...)): forward per layer, then gradients
+    tr = {n: p0[n].clone().requires_grad_(True) for n in O.trainable_names(lock)}
+    pp = dict(p0)
+    pp.update(tr)
+    upd, taps = {}, {}
+    force = {"act%d" % l.idx: l.act.float().cpu() for l in net.layers}
+    parts, _, _, _ = O.total_loss(pp, b, lock, True, perms, upd, obj_thresh=0.1, quant=O.bf16_ste, taps=taps,
+                                  force=force)
+    for l in net.layers:
+        r, amax, wmax = rel_err(l.act, taps["act%d" % l.idx])
+        assert r < 1.5e-2, "layer %d forward (teacher-forced inputs): rel l2 err %.3g" % (l.idx, r)
+    parts["total"].backward()
+    total = float(net.total_loss().cpu())
+    assert abs(total - float(parts["total"])) < 1e-3 * abs(float(parts["total"]))
+    net.backward()
+    torch.cuda.synchronize()
+    assert set(net.trainable_names()) == set(tr)
+    for name, (o, cnt) in net.arena_slices.items():
+        g = net.grad_arena[o:o + cnt].cpu()
+        want_g = tr[name].grad.flatten()
+        if name.endswith("weights") or name.endswith("biases"):
+            want_g = want_g - O.L2_WEIGHT * tr[name].detach().flatten()   # kernel adds l2*w inside Adam
+        r, amax, wmax = rel_err(g, want_g)
+        assert r < 0.05 or amax < 1e-3 * max(wmax, 1e-6), "grad %s: rel l2 err %.3g (max abs %.3g of %.3g)" % (name, r, amax, wmax)
+    # moving statistics of the training-mode BN layers
+    for name, val in upd.items():
+        r, amax, _ = rel_err(net.params[name], val)
+        assert r < 2e-2 or amax < 1e-4, "moving stat %s: rel err %.3g" % (name, r)
+    # Adam (TF form) on the kernel's own gradients
+    g_all = net.grad_arena.clone()
+    w_before = net.arena.clone()
+    net.optimizer_step()
+    torch.cuda.synchronize()
+    gg = g_all.cpu().double()
+    gg[:net.n_decay] += O.L2_WEIGHT * w_before[:net.n_decay].cpu().double()
+    wn, _, _ = O.adam_tf_step(w_before.cpu().double(), gg, torch.zeros_like(gg), torch.zeros_like(gg), 1)
+    np.testing.assert_allclose(net.arena.cpu().double().numpy(), wn.numpy(), rtol=0, atol=2e-7)
+
+
+def test_bn_act_bwd_and_small_ops(dev):
+    g = torch.Generator().manual_seed(2)
+    rows, Cc = 500, 64
+    x = torch.randn(rows, Cc, generator=g).to(torch.bfloat16)
+    dy = torch.randn(rows, Cc, generator=g).to(torch.bfloat16)
+    gamma = torch.rand(Cc, generator=g) + 0.5
+    beta = torch.randn(Cc, generator=g) * 0.2
+    xd = x.double().requires_grad_(True)
+    gm = gamma.double().requires_grad_(True)
+    bt = beta.double().requires_grad_(True)
+    mean = xd.mean(0)
+    var = ((xd - mean) ** 2).mean(0)
+    y = O.leaky_relu((xd - mean) * torch.rsqrt(var + 1e-5) * gm + bt, 0.1)
+    y.backward(dy.double())
+    rstd = (1 / torch.sqrt(var + 1e-5)).detach().float()
+    scale = (gamma * rstd)
+    shift = beta - mean.detach().float() * scale
+    dx = torch.empty(rows, Cc, dtype=torch.bfloat16, device=dev)
+    dgam, dbet = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+    L.bn_act_bwd(dy.to(dev), x.to(dev), scale.to(dev), shift.to(dev), mean.detach().float().to(dev), rstd.to(dev), dx,
+                 dgam, dbet, rows, Cc, L.Workspace(dev))
+    torch.cuda.synchronize()
+    assert rel_err(dgam, gm.grad)[0] < 1e-4
+    assert rel_err(dbet, bt.grad)[0] < 1e-4
+    assert rel_err(dx, xd.grad)[0] < 5e-3
+    # upsample backward: sum of each 2x2 block
+    src = torch.randn(2, 8, 8, 48, generator=g).to(torch.bfloat16)
+    dst = torch.zeros(2, 4, 4, 16, dtype=torch.bfloat16, device=dev)
+    L.upsample2x_bwd(src.to(dev), dst, 2, 8, 8, 48, 32, 16, accumulate=False)
+    want = src.float()[..., 32:48].reshape(2, 4, 2, 4, 2, 16).sum(dim=(2, 4))
+    torch.cuda.synchronize()
+    assert rel_err(dst, want)[0] < 5e-3
+    # column sum with ragged output width (bias gradient of a 24-channel head)
+    m = torch.randn(777, 32, generator=g).to(torch.bfloat16)
+    out = torch.zeros(24, device=dev)
+    L.colsum(m.to(dev), out, 777, 32, 24, L.Workspace(dev))
+    torch.cuda.synchronize()
+    assert rel_err(out, m.float().sum(0)[:24])[0] < 1e-5
+
+
+def test_adam_three_step_trace(dev):
+    """TF-form Adam known-answer trace: epsilon outside the bias correction."""
+    w = torch.tensor([1.0, -2.0, 0.5, 3.0], device=dev)
+    m = torch.zeros(4, device=dev)
+    v = torch.zeros(4, device=dev)
+    wr, mr, vr = w.cpu().double(), torch.zeros(4, dtype=torch.float64), torch.zeros(4, dtype=torch.float64)
+    for t in (1, 2, 3):
+        g = torch.tensor([0.1 * t, -0.2, 0.0, 1.0 / t], device=dev)
+        L.adam_step(w, g, m, v, 4, 2, 1e-4, 0.9, 0.999, 1e-8, 1e-4, t)
+        gr = g.cpu().double()
+        gr[:2] += 1e-4 * wr[:2]
+        wr, mr, vr = O.adam_tf_step(wr, gr, mr, vr, t)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(w.cpu().double().numpy(), wr.numpy(), rtol=1.2e-7, atol=0)  # 1 f32 ulp
