@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DIS-YOLO training images/sec at 576x576, bf16, on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the whole hot path over one synthetic batch that is already
+resident in HBM: forward (Darknet-53 + 3 heads + mask subnet, training-mode BN on the
+unlocked layers), detection filter (decode + per-class NMS + top-30), YOLO loss, mask-RoI
+selection + position-sensitive mask loss, backward (dgrad / wgrad / BN), Adam, weight
+re-pack -- the work of ``sess.run([total_loss, optimizer])`` (train_yolo3_mask.py:216).
+Weak scaling: 8 images per GPU; gradients are all-reduced over RCCL, overlapped with
+backward.  One JSON line is printed by rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import disyolo_amd  # noqa: F401
+from disyolo_amd import lib as L
+from disyolo_amd import config as cfg
+from disyolo_amd.net import YOLONet
+from disyolo_amd.synth import synthetic_batch
+
+# algorithmic work, SURVEY.md 8(d) / BASELINE.md 4 (FLOP = 2*Ho*Wo*Cout*Cin*k^2 over the convs)
+FWD_GFLOP_PER_IMG_576 = 132.68
+TRAIN_GFLOP_PER_IMG_576 = {1: 210.0, 2: 398.0}
+MFMA_PEAK_TFLOPS = 2500.0      # bf16 dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+
+
+def cpu_baseline(stage: int, size: int, budget_s: float = 25.0):
+    """Reference CPU path stand-in: the oracle (torch-CPU f32 restatement of the reference
+    graph; TensorFlow 1.x itself cannot run here) doing the same train step at
+    the reference's own batch size (BATCH_SIZE = 2, yolo/config.py:41)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import disyolo_oracle as O
+    B = 2
+    lock = O.default_lock(stage)
+    params = O.init_params(0, lock, xavier_locked=True)
+    batch = O.synthetic_batch(B, size, seed=1234)
+    names = O.trainable_names(lock)
+    m = {n: torch.zeros_like(params[n]) for n in names}
+    v = {n: torch.zeros_like(params[n]) for n in names}
+
+    def step(t):
+        tr = {n: params[n].clone().requires_grad_(True) for n in names}
+        pp = dict(params)
+        pp.update(tr)
+        upd = {}
+        parts, _, _, _ = O.total_loss(pp, batch, lock, True, None, upd)
+        parts["total"].backward()
+        with torch.no_grad():
+            for n in names:
+                params[n], m[n], v[n] = O.adam_tf_step(params[n], tr[n].grad, m[n], v[n], t)
+            params.update(upd)
+
+    t0 = time.time()
+    step(1)                      # warm-up (oneDNN primitive creation)
+    warm = time.time() - t0
+    n = max(1, min(5, int(budget_s / max(warm, 1e-3)) - 1))
+    t0 = time.time()
+    for i in range(n):
+        step(2 + i)
+    dt = (time.time() - t0) / n
+    return {"value": B / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d train steps of batch %d at %dx%d, stage %d, torch-CPU f32 oracle (not TF1.x); %.2f s/step"
+                      % (n, B, size, size, stage, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--size", type=int, default=576)
+    ap.add_argument("--stage", type=int, default=1, choices=(1, 2),
+                    help="1 = conv1-52 locked (the reference's shipped source), 2 = all layers trainable")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    B, S = args.batch, args.size
+    net = YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=args.stage, seed=0)
+    if world > 1:
+        from disyolo_amd.dp import enable_data_parallel
+        enable_data_parallel(net)
+    batch = synthetic_batch(B, S, seed=1234 + rank)
+    net.set_batch(batch)           # inputs resident in HBM from here on
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+
+    def step():
+        net.shuffle_rois(gen)      # tf.random_shuffle of the mask-loss RoIs, every step
+        net.train_step(None, want_loss=False)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    timer = None if args.no_kernel_events else L.KernelTimer()
+    L.TIMER = timer
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    L.TIMER = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(net.total_loss().cpu())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        train_gflop = TRAIN_GFLOP_PER_IMG_576[args.stage] * (S / 576.0) ** 2
+        out = {
+            "metric": "train images/sec @576x576 bf16",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "train_step_B%d_%dx%d_3class_stage%d" % (B, S, S, args.stage),
+                       "images_per_gpu": B, "global_batch": B * world, "image_size": S,
+                       "stage": "1: conv1-52 locked (shipped reference source)" if args.stage == 1 else
+                                "2: all 82 layers trainable",
+                       "parallelism": "dp%d" % world, "optimizer": "adam(tf-form) lr=1e-4",
+                       "final_total_loss": round(loss, 4)},
+            "model_flops": {"train_gflop_per_image": round(train_gflop, 1),
+                            "achieved_tflops_per_gpu": round(train_gflop * value / world / 1e3, 1),
+                            "frac_of_mfma_peak": round(train_gflop * value / world / 1e3 / MFMA_PEAK_TFLOPS, 4)},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            kernels = {}
+            for name, r in summ.items():
+                avg_ms = r["ms_total"] / r["launches"]
+                kernels[name] = {"launches_per_step": r["launches"] / args.steps, "avg_us": round(avg_ms * 1e3, 2),
+                                 "ms_per_step": round(r["ms_total"] / args.steps, 3),
+                                 "tflops": round(r["flops_total"] / (r["ms_total"] * 1e-3) / 1e12, 1)}
+            dom = max(summ, key=lambda k: summ[k]["ms_total"])
+            r = summ[dom]
+            achieved = r["flops_total"] / (r["ms_total"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1),
+                               "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                               "traffic": None,
+                               "flops_per_launch": round(r["flops_total"] / r["launches"] / 1e9, 3),
+                               "flops_per_launch_unit": "GFLOP (algorithmic, 2*M*N*K averaged over this kernel's launches)",
+                               "avg_launch_us": round(r["ms_total"] / r["launches"] * 1e3, 2),
+                               "launches_per_step": r["launches"] / args.steps}
+            out["kernels"] = kernels
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.stage, S)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

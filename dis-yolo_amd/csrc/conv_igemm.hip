@@ -370,6 +370,18 @@ extern "C" int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d) {
   return ceil_div(M, bm);
 }
 
+extern "C" int disyolo_conv2d_tile(const disyolo_conv_desc* d, int* bm, int* bn) {
+  if (!d) return DISYOLO_E_ARG;
+  const int id = pick_tile(d, d->B * d->Ho * d->Wo);
+  for (const TileCfg& t : kTiles)
+    if (t.id == id) {
+      if (bm) *bm = t.bm;
+      if (bn) *bn = t.bn;
+      return id;
+    }
+  return DISYOLO_E_ARG;
+}
+
 extern "C" int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream) {
   int rc = validate(d);
   if (rc) return rc;

@@ -46,6 +46,7 @@ _SIGS = {
     "disyolo_last_error": (C.c_char_p, []),
     "disyolo_conv2d_stats_rows": (C.c_int, [C.POINTER(ConvDesc)]),
     "disyolo_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "disyolo_conv2d_tile": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "disyolo_conv_first_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "disyolo_conv2d_wgrad_workspace": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "disyolo_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
@@ -176,7 +177,56 @@ def conv2d_stats_rows(d: ConvDesc) -> int:
     return r
 
 
+class KernelTimer:
+    """Brackets selected launches with HIP events on the launch stream (bench.py roofline)."""
+
+    def __init__(self):
+        self.records = {}   # name -> [flops_total, [(start, end), ...]]
+
+    def run(self, name: str, flops: float, fn) -> None:
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        rec = self.records.setdefault(name, [0.0, []])
+        rec[0] += flops
+        rec[1].append((s, e))
+
+    def summary(self):
+        out = {}
+        for name, (flops, evs) in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e in evs)
+            out[name] = {"launches": len(evs), "ms_total": ms, "flops_total": flops}
+        return out
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+def conv_flops(d: ConvDesc) -> float:
+    """algorithmic FLOPs of the convolution this descriptor belongs to: 2*M*Cout*K; for the
+    transposed (data-gradient) gather only 1/in_div^2 of the taps are real work"""
+    K = d.ksize * d.ksize * (d.C0 + d.C1)
+    return 2.0 * d.B * d.Ho * d.Wo * d.Cout * K / float(d.in_div * d.in_div)
+
+
+def conv2d_tile(d: ConvDesc):
+    bm, bn = C.c_int(0), C.c_int(0)
+    tid = load().disyolo_conv2d_tile(C.byref(d), C.byref(bm), C.byref(bn))
+    if tid < 0:
+        raise DisyoloError("conv2d_tile: bad descriptor")
+    return tid, bm.value, bn.value
+
+
 def conv2d_fwd(d: ConvDesc) -> None:
+    if TIMER is not None:
+        if not hasattr(d, "_tname"):
+            _, bm, bn = conv2d_tile(d)
+            d._tname = "conv_igemm_kernel<%d,%d>" % (bm, bn)
+        TIMER.run(d._tname, conv_flops(d), lambda: _check(load().disyolo_conv2d_fwd(C.byref(d), _stream()),
+                                                           "conv2d_fwd"))
+        return
     _check(load().disyolo_conv2d_fwd(C.byref(d), _stream()), "conv2d_fwd")
 
 
@@ -191,6 +241,12 @@ def conv_first_fwd(images, w_hwio, scale, shift, y, alpha=0.1) -> None:
 def conv2d_wgrad(d: ConvDesc, dy, dy_ld: int, dw, ws: Workspace) -> None:
     need = load().disyolo_conv2d_wgrad_workspace(C.byref(d))
     buf = ws.get(need)
+    if TIMER is not None:
+        name = "conv_wgrad_kernel<%d>" % (128 if d.Cout > 64 else (64 if d.Cout > 32 else 32))
+        TIMER.run(name, conv_flops(d), lambda: _check(
+            load().disyolo_conv2d_wgrad(C.byref(d), _p(dy), dy_ld, _p(dw), _p(buf), buf.numel(), _stream()),
+            "conv2d_wgrad"))
+        return
     _check(load().disyolo_conv2d_wgrad(C.byref(d), _p(dy), dy_ld, _p(dw), _p(buf), buf.numel(), _stream()),
            "conv2d_wgrad")
 
