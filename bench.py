@@ -87,6 +87,9 @@ def main():
                     help="1 = conv1-52 locked (the reference's shipped source), 2 = all layers trainable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--mode", default="auto", choices=("auto", "graph", "program", "eager"),
+                    help="how the step is driven: hipGraph replay of the recorded command list (1 GPU default), "
+                         "the command list cut at all-reduce points (multi-GPU default), or per-launch Python calls")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,20 +112,38 @@ def main():
         enable_data_parallel(net)
     batch = synthetic_batch(B, S, seed=1234 + rank)
     net.set_batch(batch)           # inputs resident in HBM from here on
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
+    torch.manual_seed(1234 + rank)
+    gen = None                     # default CUDA generator
+
+    mode = args.mode
+    if mode == "auto":
+        mode = "graph" if world == 1 else "program"
 
     def step():
         net.shuffle_rois(gen)      # tf.random_shuffle of the mask-loss RoIs, every step
         net.train_step(None, want_loss=False)
 
+    # per-kernel durations for the roofline: HIP events around every conv launch over K eager
+    # steps of the same workload (events cannot time nodes inside a graph replay; the kernels
+    # and their arguments are identical in all three modes)
+    timer = None
+    if not args.no_kernel_events:      # every rank runs these steps (they contain the collectives)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        timer = L.KernelTimer()
+        L.TIMER = timer
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        L.TIMER = None
+    if mode != "eager":
+        net.build_program(graph=(mode == "graph"))
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    timer = None if args.no_kernel_events else L.KernelTimer()
-    L.TIMER = timer
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -132,7 +153,6 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    L.TIMER = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -152,7 +172,7 @@ def main():
                        "images_per_gpu": B, "global_batch": B * world, "image_size": S,
                        "stage": "1: conv1-52 locked (shipped reference source)" if args.stage == 1 else
                                 "2: all 82 layers trainable",
-                       "parallelism": "dp%d" % world, "optimizer": "adam(tf-form) lr=1e-4",
+                       "parallelism": "dp%d" % world, "optimizer": "adam(tf-form) lr=1e-4", "step_driver": mode,
                        "final_total_loss": round(loss, 4)},
             "model_flops": {"train_gflop_per_image": round(train_gflop, 1),
                             "achieved_tflops_per_gpu": round(train_gflop * value / world / 1e3, 1),
@@ -169,7 +189,7 @@ def main():
             dom = max(summ, key=lambda k: summ[k]["ms_total"])
             r = summ[dom]
             achieved = r["flops_total"] / (r["ms_total"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1),
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "timed_with": "HIP events, %d eager steps of the same workload" % args.steps, "achieved": round(achieved, 1),
                                "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                                "traffic": None,
                                "flops_per_launch": round(r["flops_total"] / r["launches"] / 1e9, 3),

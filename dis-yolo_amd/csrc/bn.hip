@@ -5,33 +5,25 @@
 // Replaces tf.nn.moments / tf.nn.batch_normalization / tf.assign(moving stats) /
 // tf.maximum(alpha*x, x) and their TF-autodiff gradients, yolo/yolo3_net_pos.py:68-107.
 #include "common.h"
+#include "runtime.h"
 
 namespace {
 
 // ---- stage 2 of every column reduction: partial[rows][C][Q] -> f64 sums ------------
-template <int Q>
-__device__ __forceinline__ void sum_partials(const float* part, int rows, int C, int c, double* out) {
-  // called by a group of 8 threads per channel (sub = 0..7), result valid in sub == 0
-  // after the LDS combine done by the caller
-#pragma unroll
-  for (int q = 0; q < Q; ++q) out[q] = 0.0;
-  for (int r = 0; r < rows; ++r) {
-#pragma unroll
-    for (int q = 0; q < Q; ++q) out[q] += (double)part[((size_t)r * C + c) * Q + q];
-  }
-}
-
-// 256 threads = 32 channels x 8 row groups; each group strides over the partial rows.
+// 256 threads = 8 channels x 32 row lanes; each lane strides over the partial rows, the
+// 32 lane sums are combined through LDS in a fixed order (deterministic).
+constexpr int FIN_CPB = 8;
 template <int Q>
 __device__ __forceinline__ bool block_sum_partials(const float* part, int rows, int C, double* res /*[Q]*/, int* c_out) {
-  __shared__ double sh[8][32][Q];
-  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  constexpr int LANES = 256 / FIN_CPB;
+  __shared__ double sh[LANES][FIN_CPB][Q];
+  const int cl = threadIdx.x % FIN_CPB, g = threadIdx.x / FIN_CPB;
+  const int c = blockIdx.x * FIN_CPB + cl;
   double acc[Q];
 #pragma unroll
   for (int q = 0; q < Q; ++q) acc[q] = 0.0;
   if (c < C) {
-    for (int r = g; r < rows; r += 8) {
+    for (int r = g; r < rows; r += LANES) {
 #pragma unroll
       for (int q = 0; q < Q; ++q) acc[q] += (double)part[((size_t)r * C + c) * Q + q];
     }
@@ -45,7 +37,7 @@ __device__ __forceinline__ bool block_sum_partials(const float* part, int rows, 
     for (int q = 0; q < Q; ++q) {
       double s = 0.0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s += sh[k][cl][q];
+      for (int k = 0; k < LANES; ++k) s += sh[k][cl][q];
       res[q] = s;
     }
     return true;
@@ -194,36 +186,44 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part,
   if (c < out_C) out[c] = (float)r[0];
 }
 
+// dx = scale*(g - mean(g) - xhat*mean(g*xhat)) = scale*g - x*A + Cc with
+// A = scale*rstd*mean(g*xhat), Cc = mean*A - scale*mean(g)
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part, int rows, int C, double inv_count,
-                                                              float* dgamma, float* dbeta, float* c1, float* c2) {
+                                                              const float* scale, const float* mean, const float* rstd,
+                                                              float* dgamma, float* dbeta, float* cA, float* cC) {
   double r[2];
   int c;
   if (!block_sum_partials<2>(part, rows, C, r, &c)) return;
   dbeta[c] = (float)r[0];
   dgamma[c] = (float)r[1];
-  c1[c] = (float)(r[0] * inv_count);
-  c2[c] = (float)(r[1] * inv_count);
+  const float c1 = (float)(r[0] * inv_count), c2 = (float)(r[1] * inv_count);
+  const float A = scale[c] * rstd[c] * c2;
+  cA[c] = A;
+  cC[c] = mean[c] * A - scale[c] * c1;
 }
 
-// dx = scale * (g - mean(g) - xhat * mean(g*xhat))
+__device__ __forceinline__ void load8(const float* p, float* o) {
+  const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = c.x; o[5] = c.y; o[6] = c.z; o[7] = c.w;
+}
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint4* dy, const uint4* x, const float* scale,
-                                                           const float* shift, const float* mean, const float* rstd,
-                                                           const float* c1, const float* c2, uint4* dx, int64_t nvec,
-                                                           int C, float alpha) {
+                                                           const float* shift, const float* cA, const float* cC,
+                                                           uint4* dx, int64_t nvec, int C, float alpha) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
     const int c0 = (int)((i * 8) % C);
-    float g[8], vx[8];
+    float g[8], vx[8], sc[8], sh[8], A[8], Cc[8];
     unpack8(dy[i], g);
     unpack8(x[i], vx);
+    load8(scale + c0, sc);
+    load8(shift + c0, sh);
+    load8(cA + c0, A);
+    load8(cC + c0, Cc);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int c = c0 + k;
-      const float sc = scale[c];
-      const float z = vx[k] * sc + shift[c];
+      const float z = vx[k] * sc[k] + sh[k];
       const float gg = g[k] * (z > 0.f ? 1.f : alpha);
-      const float xh = (vx[k] - mean[c]) * rstd[c];
-      g[k] = sc * (gg - c1[c] - xh * c2[c]);
+      g[k] = sc[k] * gg - vx[k] * A[k] + Cc[k];
     }
     dx[i] = pack8(g);
   }
@@ -298,7 +298,8 @@ extern "C" int disyolo_bn_finalize(const float* stats, int rows, int C, int64_t 
                                    const float* beta, float* moving_mean, float* moving_var, float decay, float eps,
                                    float* scale, float* shift, float* mean, float* rstd, void* stream) {
   DY_REQUIRE(stats && gamma && beta && scale && shift && rows > 0 && C > 0 && count > 0, "bn_finalize: bad args");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream, stats, rows, C,
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_bn_finalize(stats, rows, C, count, gamma, beta, moving_mean, moving_var, decay, eps, scale, shift, mean, rstd, s); });
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, FIN_CPB)), dim3(256), 0, (hipStream_t)stream, stats, rows, C,
                      1.0 / (double)count, gamma, beta, moving_mean, moving_var, decay, eps, scale, shift, mean, rstd);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
@@ -307,6 +308,7 @@ extern "C" int disyolo_bn_finalize(const float* stats, int rows, int C, int64_t 
 extern "C" int disyolo_bn_fold(const float* gamma, const float* beta, const float* moving_mean,
                                const float* moving_var, float eps, float* scale, float* shift, int C, void* stream) {
   DY_REQUIRE(gamma && beta && moving_mean && moving_var && scale && shift && C > 0, "bn_fold: bad args");
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_bn_fold(gamma, beta, moving_mean, moving_var, eps, scale, shift, C, s); });
   hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
                      moving_mean, moving_var, eps, scale, shift, C);
   DY_CHECK_LAUNCH();
@@ -316,6 +318,7 @@ extern "C" int disyolo_bn_fold(const float* gamma, const float* beta, const floa
 extern "C" int disyolo_bn_act_fwd(const void* x, const float* scale, const float* shift, const void* residual, void* y,
                                   int64_t rows, int C, float alpha, void* stream) {
   DY_REQUIRE(x && scale && shift && y && rows > 0 && C > 0 && C % 8 == 0, "bn_act_fwd: bad args (C %% 8 == 0)");
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_bn_act_fwd(x, scale, shift, residual, y, rows, C, alpha, s); });
   const int64_t nvec = rows * C / 8;
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const uint4*)x,
                      scale, shift, (const uint4*)residual, (uint4*)y, nvec, C, alpha);
@@ -338,6 +341,7 @@ extern "C" int disyolo_bn_act_bwd(const void* dy, const void* x, const float* sc
     disyolo_set_error("bn_act_bwd: workspace too small");
     return DISYOLO_E_WORKSPACE;
   }
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_bn_act_bwd(dy, x, scale, shift, mean, rstd, dx, dgamma, dbeta, rows, C, alpha, workspace, workspace_bytes, s); });
   hipStream_t s = (hipStream_t)stream;
   const int nb = colreduce_blocks(rows, C), rpb = colreduce_rpb(rows, C);
   const int chunks = C / 8, cpb = chunks < 256 ? chunks : 256;
@@ -347,12 +351,12 @@ extern "C" int disyolo_bn_act_bwd(const void* dy, const void* x, const float* sc
   hipLaunchKernelGGL(colreduce_kernel<1>, dim3(nb, ceil_div(chunks, cpb)), dim3(256), 0, s, (const uint4*)dy,
                      (const uint4*)x, scale, shift, mean, rstd, alpha, rows, C, rpb, part);
   DY_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, s, part, nb, C, 1.0 / (double)rows,
-                     dgamma, dbeta, c1, c2);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_CPB)), dim3(256), 0, s, part, nb, C, 1.0 / (double)rows,
+                     scale, mean, rstd, dgamma, dbeta, c1, c2);
   DY_CHECK_LAUNCH();
   const int64_t nvec = rows * C / 8;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nvec)), dim3(256), 0, s, (const uint4*)dy, (const uint4*)x,
-                     scale, shift, mean, rstd, c1, c2, (uint4*)dx, nvec, C, alpha);
+                     scale, shift, c1, c2, (uint4*)dx, nvec, C, alpha);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }
@@ -361,6 +365,7 @@ extern "C" int disyolo_upsample2x_bwd(const void* src, void* dst, int B, int Hs,
                                       int accumulate, void* stream) {
   DY_REQUIRE(src && dst && B > 0 && Hs > 0 && Ws > 0 && Hs % 2 == 0 && Ws % 2 == 0, "upsample2x_bwd: bad sizes");
   DY_REQUIRE(C > 0 && C % 8 == 0 && c_off % 8 == 0 && c_off + C <= src_C && src_C % 8 == 0, "upsample2x_bwd: bad channels");
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_upsample2x_bwd(src, dst, B, Hs, Ws, src_C, c_off, C, accumulate, s); });
   const int64_t nvec = (int64_t)B * (Hs / 2) * (Ws / 2) * (C / 8);
   hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src,
                      (bf16*)dst, B, Hs, Ws, src_C, c_off, C, accumulate);
@@ -380,13 +385,14 @@ extern "C" int disyolo_colsum(const void* x, float* out, int64_t rows, int C, in
     disyolo_set_error("colsum: workspace too small");
     return DISYOLO_E_WORKSPACE;
   }
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_colsum(x, out, rows, C, out_C, workspace, workspace_bytes, s); });
   hipStream_t s = (hipStream_t)stream;
   const int nb = colreduce_blocks(rows, C), rpb = colreduce_rpb(rows, C);
   const int chunks = C / 8, cpb = chunks < 256 ? chunks : 256;
   hipLaunchKernelGGL(colreduce_kernel<0>, dim3(nb, ceil_div(chunks, cpb)), dim3(256), 0, s, (const uint4*)x,
                      (const uint4*)nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, rows, C, rpb, (float*)workspace);
   DY_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, s, (const float*)workspace, nb, C,
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, FIN_CPB)), dim3(256), 0, s, (const float*)workspace, nb, C,
                      out_C, out);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
@@ -399,6 +405,7 @@ extern "C" int disyolo_colstats_rows(int64_t rows, int C) {
 
 extern "C" int disyolo_colstats(const void* x, float* stats, int64_t rows, int C, void* stream) {
   DY_REQUIRE(x && stats && rows > 0 && C > 0 && C % 8 == 0, "colstats: bad args (C %% 8 == 0)");
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_colstats(x, stats, rows, C, s); });
   const int nb = colreduce_blocks(rows, C), rpb = colreduce_rpb(rows, C);
   const int chunks = C / 8, cpb = chunks < 256 ? chunks : 256;
   hipLaunchKernelGGL(colreduce_kernel<2>, dim3(nb, ceil_div(chunks, cpb)), dim3(256), 0, (hipStream_t)stream,

@@ -14,6 +14,7 @@
 // bf16); the 16-byte chunk index is XOR-swizzled so ds_read_b128 fragment reads are
 // bank-conflict free (see DESIGN.md "LDS layout").
 #include "common.h"
+#include "runtime.h"
 
 namespace {
 
@@ -386,6 +387,10 @@ extern "C" int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream) {
   int rc = validate(d);
   if (rc) return rc;
   DY_REQUIRE(!(d->flags & DISYOLO_CONV_STATS) || d->stats, "conv: STATS flag without stats buffer");
+  {
+    const disyolo_conv_desc c = *d;
+    DY_RECORD_OR_RUN([c](void* s) { return disyolo_conv2d_fwd(&c, s); });
+  }
   ConvParams p;
   p.x0 = (const bf16*)d->x0;
   p.x1 = (const bf16*)d->x1;

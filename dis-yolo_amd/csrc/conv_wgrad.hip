@@ -10,6 +10,7 @@
 // The pixel range is split over blockIdx.z; each split writes an f32 slab and a second
 // kernel adds the slabs in a fixed order (deterministic, no float atomics).
 #include "common.h"
+#include "runtime.h"
 
 namespace {
 
@@ -258,7 +259,7 @@ void plan(const disyolo_conv_desc* d, int* bn, int* splits, int* steps_per_split
   *bn = d->Cout > 64 ? 128 : (d->Cout > 32 ? 64 : 32);
   const int tiles = ceil_div(K, 128) * ceil_div(d->Cout, *bn);
   *steps = ceil_div(M, 32);
-  int s = 1024 / tiles;
+  int s = 512 / tiles;  // fill the 256 CUs about twice; a full grid needs no pixel split
   if (s < 1) s = 1;
   const int max_s = ceil_div(*steps, 8);
   if (s > max_s) s = max_s;
@@ -288,6 +289,10 @@ extern "C" int disyolo_conv2d_wgrad(const disyolo_conv_desc* d, const void* dy, 
   if (!workspace || workspace_bytes < disyolo_conv2d_wgrad_workspace(d)) {
     disyolo_set_error("wgrad: workspace too small");
     return DISYOLO_E_WORKSPACE;
+  }
+  {
+    const disyolo_conv_desc c = *d;
+    DY_RECORD_OR_RUN([=](void* s) { return disyolo_conv2d_wgrad(&c, dy, dy_ld, dw, workspace, workspace_bytes, s); });
   }
   WgradParams p;
   p.x0 = (const bf16*)d->x0;
@@ -333,6 +338,7 @@ extern "C" int disyolo_conv_first_wgrad(const float* images, const void* dy, flo
     disyolo_set_error("first_wgrad: workspace too small");
     return DISYOLO_E_WORKSPACE;
   }
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_conv_first_wgrad(images, dy, dw, B, H, W, Cout, workspace, workspace_bytes, s); });
   const int64_t M = (int64_t)B * H * W;
   const int blocks = ceil_div(M, 1024);
   hipStream_t s = (hipStream_t)stream;

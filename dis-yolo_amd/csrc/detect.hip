@@ -3,7 +3,9 @@
 // Replaces interpret_output / filter_detections / clip_boxes_graph / val_test of
 // yolo/yolo3_net_pos.py:465-628, 862-952 (the reference unrolls these per image in Python
 // and runs tf.image.non_max_suppression per class through tf.map_fn).
+#include <array>
 #include "common.h"
+#include "runtime.h"
 
 namespace {
 
@@ -80,38 +82,98 @@ __device__ __forceinline__ float nms_iou(const float4& a, const float4& b) {
   return inter / (aa + ab - inter);
 }
 
-// One block per image: threshold + ordered compaction, per-class greedy NMS (IoU > thr
-// suppresses, <= max_det kept per class), then the top max_det by score (ties: lower
-// candidate index), zero padded.  Exact for any number of candidates: selection is a
-// repeated block-wide arg-max over the live list, never a truncated sort.
+// Detection filter.  Stage 1: one block per (image, class): ordered compaction of the
+// candidates with score > thr and arg-max class == c, then greedy NMS (IoU > nms_thr
+// suppresses, at most max_det kept) as a repeated block-wide arg-max over the live list --
+// exact for any number of candidates, never a truncated sort.  Scores/boxes of the live
+// list sit in LDS when they fit (<= NMS_CAP), else in the global workspace.  Stage 2: one
+// block per image merges the per-class survivors: top max_det by score (ties: lower
+// candidate index), zero padded.
 constexpr int NMS_T = 256;
+constexpr int NMS_CAP = 3072;
 constexpr int MAX_KEEP = 512;  // >= num_class * max_det
-__global__ __launch_bounds__(NMS_T) void nms_kernel(const float4* boxes, const float* scores, const int* classes,
-                                                    int NC, int C, float thr, float nms_thr, int max_det, int* list,
-                                                    float* live, float* det, int* det_count) {
-  const int b = blockIdx.x, tid = threadIdx.x;
+
+template <bool IN_LDS>
+__device__ __forceinline__ int greedy_nms(int n, const int* list, const float4* boxes, float* live, float4* lbox,
+                                          float nms_thr, int max_det, int* kept_idx, float* kept_sc, float* s_ws,
+                                          int* s_wp) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int nk = 0;
+  for (int it = 0; it < max_det; ++it) {
+    float bs = -1.f;
+    int bp = 0x7fffffff;
+    for (int q = tid; q < n; q += NMS_T) {
+      const float v = live[q];
+      if (v > bs) {  // ascending scan: lowest position wins among equal scores
+        bs = v;
+        bp = q;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(bs, o, 64);
+      const int p2 = __shfl_xor(bp, o, 64);
+      if (v2 > bs || (v2 == bs && p2 < bp)) {
+        bs = v2;
+        bp = p2;
+      }
+    }
+    if (lane == 0) {
+      s_ws[wv] = bs;
+      s_wp[wv] = bp;
+    }
+    __syncthreads();
+    float wsc = s_ws[0];
+    int wq = s_wp[0];
+#pragma unroll
+    for (int w = 1; w < NMS_T / 64; ++w) {
+      const float v2 = s_ws[w];
+      const int p2 = s_wp[w];
+      if (v2 > wsc || (v2 == wsc && p2 < wq)) {
+        wsc = v2;
+        wq = p2;
+      }
+    }
+    if (!(wsc > 0.f)) break;  // nothing alive (live scores are > thr >= 0); uniform exit
+    const float4 wb = IN_LDS ? lbox[wq] : boxes[list[wq]];
+    if (tid == 0) {
+      kept_idx[nk] = list[wq];
+      kept_sc[nk] = wsc;
+    }
+    ++nk;
+    for (int q = tid; q < n; q += NMS_T) {
+      if (live[q] >= 0.f) {
+        const float4 bx = IN_LDS ? lbox[q] : boxes[list[q]];
+        if (q == wq || nms_iou(bx, wb) > nms_thr) live[q] = -1.f;
+      }
+    }
+    __syncthreads();
+  }
+  return nk;
+}
+
+__global__ __launch_bounds__(NMS_T) void nms_class_kernel(const float4* boxes, const float* scores, const int* classes,
+                                                          int NC, int C, float thr, float nms_thr, int max_det,
+                                                          int* list_g, float* live_g, int* kept_idx, float* kept_sc,
+                                                          int* kept_n) {
+  const int b = blockIdx.x / C, c = blockIdx.x - b * C, tid = threadIdx.x;
   boxes += (size_t)b * NC;
   scores += (size_t)b * NC;
   classes += (size_t)b * NC;
-  list += (size_t)b * NC;
-  live += (size_t)b * NC;
+  int* list = list_g + (size_t)blockIdx.x * NC;
+  float* live_glob = live_g + (size_t)blockIdx.x * NC;
+  kept_idx += (size_t)blockIdx.x * max_det;
+  kept_sc += (size_t)blockIdx.x * max_det;
   __shared__ int s_wcnt[2][NMS_T / 64];
-  __shared__ int s_n;
-  __shared__ float s_bs[NMS_T];
-  __shared__ int s_bp[NMS_T];
-  __shared__ int s_keep_idx[MAX_KEEP];
-  __shared__ float s_keep_sc[MAX_KEEP];
-  __shared__ int s_nkeep;
-  if (tid == 0) {
-    s_n = 0;
-    s_nkeep = 0;
-  }
-  __syncthreads();
-  // ---- ordered compaction of candidates with score > thr (wave ballots + one barrier)
+  __shared__ float s_ws[NMS_T / 64];
+  __shared__ int s_wp[NMS_T / 64];
+  __shared__ float s_live[NMS_CAP];
+  __shared__ float4 s_box[NMS_CAP];
+  // ---- ordered compaction (wave ballots + one barrier per 256 candidates)
   int total = 0;
   for (int base = 0, it = 0; base < NC; base += NMS_T, ++it) {
     const int i = base + tid;
-    const bool f = (i < NC) && (scores[i] > thr);
+    const bool f = (i < NC) && (scores[i] > thr) && (classes[i] == c);
     const unsigned long long mask = __ballot(f);
     const int lane = tid & 63, wv = tid >> 6;
     if (lane == 0) s_wcnt[it & 1][wv] = __popcll(mask);
@@ -125,72 +187,60 @@ __global__ __launch_bounds__(NMS_T) void nms_kernel(const float4* boxes, const f
     }
     if (f) list[off + __popcll(mask & ((1ull << lane) - 1ull))] = i;
   }
-  if (tid == 0) s_n = total;
-  __syncthreads();
-  const int n = s_n;
-  __threadfence_block();
-  // ---- per-class greedy NMS
-  for (int c = 0; c < C; ++c) {
+  __syncthreads();  // list[] (global) written by this block, read below by all its threads
+  const int n = total;
+  int nk;
+  if (n <= NMS_CAP) {
     for (int q = tid; q < n; q += NMS_T) {
       const int i = list[q];
-      live[q] = classes[i] == c ? scores[i] : -1.f;
+      s_live[q] = scores[i];
+      s_box[q] = boxes[i];
     }
     __syncthreads();
-    for (int it = 0; it < max_det; ++it) {
-      float bs = -1.f;
-      int bp = 0x7fffffff;
-      for (int q = tid; q < n; q += NMS_T) {
-        const float v = live[q];
-        if (v > bs) {  // strided scan keeps the lowest position among equal scores
-          bs = v;
-          bp = q;
-        }
-      }
-      s_bs[tid] = bs;
-      s_bp[tid] = bp;
-      __syncthreads();
-      for (int o = NMS_T / 2; o > 0; o >>= 1) {
-        if (tid < o) {
-          const float v2 = s_bs[tid + o];
-          const int p2 = s_bp[tid + o];
-          if (v2 > s_bs[tid] || (v2 == s_bs[tid] && p2 < s_bp[tid])) {
-            s_bs[tid] = v2;
-            s_bp[tid] = p2;
-          }
-        }
-        __syncthreads();
-      }
-      const float wsc = s_bs[0];
-      const int wq = s_bp[0];
-      __syncthreads();
-      if (!(wsc > 0.f)) break;  // nothing alive (scores are > thr >= 0)... uniform exit
-      const int wi = list[wq];
-      const float4 wb = boxes[wi];
-      if (tid == 0) {
-        s_keep_idx[s_nkeep] = wi;
-        s_keep_sc[s_nkeep] = wsc;
-        ++s_nkeep;
-      }
-      for (int q = tid; q < n; q += NMS_T) {
-        if (live[q] >= 0.f) {
-          if (q == wq || nms_iou(boxes[list[q]], wb) > nms_thr) live[q] = -1.f;
-        }
-      }
-      __syncthreads();
-    }
+    nk = greedy_nms<true>(n, list, boxes, s_live, s_box, nms_thr, max_det, kept_idx, kept_sc, s_ws, s_wp);
+  } else {
+    for (int q = tid; q < n; q += NMS_T) live_glob[q] = scores[list[q]];
     __syncthreads();
+    nk = greedy_nms<false>(n, list, boxes, live_glob, nullptr, nms_thr, max_det, kept_idx, kept_sc, s_ws, s_wp);
   }
-  // ---- top max_det of the kept set: score descending, ties by lower candidate index
-  const int nk = s_nkeep;
-  for (int r = tid; r < max_det * 6; r += NMS_T) det[(size_t)b * max_det * 6 + r] = 0.f;
+  if (tid == 0) kept_n[blockIdx.x] = nk;
+}
+
+__global__ __launch_bounds__(64) void nms_merge_kernel(const float4* boxes, const int* classes, int NC, int C,
+                                                       int max_det, const int* kept_idx, const float* kept_sc,
+                                                       const int* kept_n, float* det, int* det_count) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  boxes += (size_t)b * NC;
+  classes += (size_t)b * NC;
+  __shared__ int s_idx[MAX_KEEP];
+  __shared__ float s_sc[MAX_KEEP];
+  __shared__ int s_off[17];
+  if (tid == 0) {
+    int o = 0;
+    for (int c = 0; c < C; ++c) {
+      s_off[c] = o;
+      o += kept_n[b * C + c];
+    }
+    s_off[C] = o;
+  }
   __syncthreads();
-  for (int k = tid; k < nk; k += NMS_T) {
-    const float sc = s_keep_sc[k];
-    const int ix = s_keep_idx[k];
+  const int nk = s_off[C];
+  for (int c = 0; c < C; ++c) {
+    const int cn = s_off[c + 1] - s_off[c];
+    for (int k = tid; k < cn; k += 64) {
+      s_idx[s_off[c] + k] = kept_idx[((size_t)b * C + c) * max_det + k];
+      s_sc[s_off[c] + k] = kept_sc[((size_t)b * C + c) * max_det + k];
+    }
+  }
+  for (int r = tid; r < max_det * 6; r += 64) det[(size_t)b * max_det * 6 + r] = 0.f;
+  __syncthreads();
+  for (int k = tid; k < nk; k += 64) {
+    const float sc = s_sc[k];
+    const int ix = s_idx[k];
     int rank = 0;
     for (int j = 0; j < nk; ++j) {
-      const float sj = s_keep_sc[j];
-      if (sj > sc || (sj == sc && s_keep_idx[j] < ix)) ++rank;
+      const float sj = s_sc[j];
+      if (sj > sc || (sj == sc && s_idx[j] < ix)) ++rank;
     }
     if (rank < max_det) {
       float* o = det + ((size_t)b * max_det + rank) * 6;
@@ -254,8 +304,8 @@ extern "C" size_t disyolo_detect_workspace(int B, int S, int num_class) {
   if (B <= 0 || S <= 0 || S % 32) return 0;
   const int g1 = S / 32;
   const size_t NC = 3 * (size_t)(16 * g1 * g1 + 4 * g1 * g1 + g1 * g1);
-  // boxes (16 B) + scores + classes + list + live
-  return (size_t)B * NC * (16 + 4 + 4 + 4 + 4);
+  // boxes (16 B) + scores + classes, per-class list + live, per-class kept (idx, score, n)
+  return (size_t)B * NC * (16 + 4 + 4) + (size_t)B * num_class * NC * 8 + (size_t)B * num_class * (64 * 8 + 4) + 256;
 }
 
 extern "C" int disyolo_detect(const float* logits3, const float* logits2, const float* logits1, int B, int S,
@@ -265,11 +315,19 @@ extern "C" int disyolo_detect(const float* logits3, const float* logits2, const 
   DY_REQUIRE(logits3 && logits2 && logits1 && anchors_host && clip_window && detections && det_count,
              "detect: null pointer");
   DY_REQUIRE(B > 0 && S > 0 && S % 32 == 0 && num_class > 0 && num_class <= 16, "detect: bad sizes");
-  DY_REQUIRE(max_det > 0 && num_class * max_det <= MAX_KEEP, "detect: num_class*max_det > %d", MAX_KEEP);
+  DY_REQUIRE(max_det > 0 && max_det <= 64 && num_class * max_det <= MAX_KEEP, "detect: max_det must be <= 64");
   DY_REQUIRE(obj_thresh >= 0.f, "detect: obj_thresh must be >= 0");
   if (!workspace || workspace_bytes < disyolo_detect_workspace(B, S, num_class)) {
     disyolo_set_error("detect: workspace too small");
     return DISYOLO_E_WORKSPACE;
+  }
+  {
+    std::array<float, 18> anc;
+    for (int i = 0; i < 18; ++i) anc[i] = anchors_host[i];
+    DY_RECORD_OR_RUN([=](void* s) {
+      return disyolo_detect(logits3, logits2, logits1, B, S, num_class, anc.data(), clip_window, obj_thresh, nms_thresh,
+                            max_det, detections, det_count, workspace, workspace_bytes, s);
+    });
   }
   const int g1 = S / 32;
   DecodeParams p;
@@ -292,13 +350,19 @@ extern "C" int disyolo_detect(const float* logits3, const float* logits2, const 
   p.boxes = (float4*)ws;                  ws += (size_t)B * c0 * 16;
   p.scores = (float*)ws;                  ws += (size_t)B * c0 * 4;
   p.classes = (int*)ws;                   ws += (size_t)B * c0 * 4;
-  int* list = (int*)ws;                   ws += (size_t)B * c0 * 4;
-  float* live = (float*)ws;
+  int* list = (int*)ws;                   ws += (size_t)B * num_class * c0 * 4;
+  float* live = (float*)ws;               ws += (size_t)B * num_class * c0 * 4;
+  int* kept_idx = (int*)ws;               ws += (size_t)B * num_class * 64 * 4;
+  float* kept_sc = (float*)ws;            ws += (size_t)B * num_class * 64 * 4;
+  int* kept_n = (int*)ws;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(decode_score_kernel, dim3(ceil_div(c0, 256), B), dim3(256), 0, st, p);
   DY_CHECK_LAUNCH();
-  hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NMS_T), 0, st, p.boxes, p.scores, p.classes, c0, num_class, obj_thresh,
-                     nms_thresh, max_det, list, live, detections, det_count);
+  hipLaunchKernelGGL(nms_class_kernel, dim3(B * num_class), dim3(NMS_T), 0, st, p.boxes, p.scores, p.classes, c0,
+                     num_class, obj_thresh, nms_thresh, max_det, list, live, kept_idx, kept_sc, kept_n);
+  DY_CHECK_LAUNCH();
+  hipLaunchKernelGGL(nms_merge_kernel, dim3(B), dim3(64), 0, st, p.boxes, p.classes, c0, num_class, max_det, kept_idx,
+                     kept_sc, kept_n, detections, det_count);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }
@@ -307,6 +371,7 @@ extern "C" int disyolo_psroi_assemble(const float* score, const float* detection
                                       int k, float* masks, int32_t* keep, void* stream) {
   DY_REQUIRE(score && detections && masks && keep && B > 0 && max_det > 0 && map_size > 0, "psroi_assemble: bad args");
   DY_REQUIRE(k == 3, "psroi_assemble: only k = 3 (the reference's active branch, yolo/yolo3_net_pos.py:894-897)");
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_psroi_assemble(score, detections, B, max_det, map_size, k, masks, keep, s); });
   const int npx = map_size * map_size;
   int gx = ceil_div(npx, 256 * 4);
   if (gx < 1) gx = 1;

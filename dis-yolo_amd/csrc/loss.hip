@@ -8,7 +8,9 @@
 // Gradients wrt head logits / score maps are written as bf16 rows padded to 32 channels
 // (zeros beyond the real channels) so they feed the MFMA data/weight-gradient convs
 // directly.  Scalar losses use per-block partials + a fixed-order final sum.
+#include <array>
 #include "common.h"
+#include "runtime.h"
 
 namespace {
 
@@ -369,6 +371,17 @@ extern "C" int disyolo_yolo_loss(const float* const logits[3], const float* cons
     disyolo_set_error("yolo_loss: workspace too small");
     return DISYOLO_E_WORKSPACE;
   }
+  {
+    std::array<float, 18> anc;
+    for (int i = 0; i < 18; ++i) anc[i] = anchors_host[i];
+    std::array<float, 4> sc4 = {scales[0], scales[1], scales[2], scales[3]};
+    std::array<const float*, 3> lg = {logits[0], logits[1], logits[2]}, lb = {labels[0], labels[1], labels[2]};
+    std::array<void*, 3> dl = {dlogits[0], dlogits[1], dlogits[2]};
+    DY_RECORD_OR_RUN([=](void* s) {
+      return disyolo_yolo_loss(lg.data(), lb.data(), true_boxes, max_boxes, B, S, num_class, anc.data(), ignore_thresh,
+                               sc4.data(), dl.data(), losses, workspace, workspace_bytes, s);
+    });
+  }
   hipStream_t st = (hipStream_t)stream;
   const int g1 = S / 32;
   const int gs[3] = {4 * g1, 2 * g1, g1};
@@ -408,6 +421,10 @@ extern "C" int disyolo_mask_rois(const float* detections, int max_det, const flo
   DY_REQUIRE(detections && true_boxes && rois && roi_count, "mask_rois: null pointer");
   DY_REQUIRE(B > 0 && max_det > 0 && max_det <= 64 && G > 0 && G <= 64 && map_size > 0, "mask_rois: bad sizes");
   DY_REQUIRE(n_det >= 0 && n_gt >= 0 && n_det + n_gt <= ROI_MAX, "mask_rois: n_det + n_gt > %d", ROI_MAX);
+  DY_RECORD_OR_RUN([=](void* s) {
+    return disyolo_mask_rois(detections, max_det, true_boxes, G, perm_det, perm_gt, B, map_size, n_det, n_gt, iou_thresh,
+                             rois, roi_count, s);
+  });
   hipLaunchKernelGGL(mask_rois_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, detections, max_det,
                      true_boxes, G, perm_det, perm_gt, B, map_size, n_det, n_gt, iou_thresh, rois, roi_count);
   DY_CHECK_LAUNCH();
@@ -429,6 +446,10 @@ extern "C" int disyolo_psroi_loss(const float* score, const uint8_t* true_masks,
     disyolo_set_error("psroi_loss: workspace too small");
     return DISYOLO_E_WORKSPACE;
   }
+  DY_RECORD_OR_RUN([=](void* s) {
+    return disyolo_psroi_loss(score, true_masks, G, rois, roi_count, B, map_size, k, mask_scale, dscore, loss, workspace,
+                              workspace_bytes, s);
+  });
   hipStream_t st = (hipStream_t)stream;
   const int nblk = ceil_div((size_t)map_size * map_size, 256);
   hipLaunchKernelGGL(psroi_loss_kernel, dim3(nblk, B), dim3(256), 0, st, score, true_masks, G, rois, roi_count, B,

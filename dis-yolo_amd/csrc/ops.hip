@@ -1,6 +1,7 @@
 // First-layer convolution, weight packing, Adam and the l2 term.
 #include <stdarg.h>
 #include "common.h"
+#include "runtime.h"
 
 // ---- error reporting -------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -113,6 +114,29 @@ __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, flo
   }
 }
 
+// same, with the step count t = *counter + 1 read from device memory (graph / command-list
+// replay: the host never touches the step), and the counter bumped by a trailing kernel
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* w, const float* g, float* m, float* v, int64_t n,
+                                                       int64_t n_decay, float lr, float b1, float b2, float eps,
+                                                       float l2, float gscale, const int64_t* counter) {
+  const double t = (double)(*counter + 1);
+  const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float wi = w[i];
+    float gi = g[i] * gscale;
+    if (i < n_decay) gi += l2 * wi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    w[i] = wi - lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+__global__ void bump_counter_kernel(int64_t* counter) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *counter += 1;
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* w, int64_t n, float* part) {
   __shared__ float sh[4];
   float acc = 0.f;
@@ -138,6 +162,7 @@ extern "C" int disyolo_conv_first_fwd(const float* images, const float* w_hwio, 
                                       void* stream) {
   DY_REQUIRE(images && w_hwio && scale && shift && y_bf16 && B > 0 && H > 0 && W > 0, "conv_first: bad args");
   DY_REQUIRE(Cout == 32, "conv_first: Cout must be 32 (got %d)", Cout);
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_conv_first_fwd(images, w_hwio, scale, shift, y_bf16, B, H, W, Cout, alpha, s); });
   const int64_t total = (int64_t)B * H * W * (Cout / 8);
   int grid = ceil_div(total, 256);
   if (grid > 256 * 16) grid = 256 * 16;
@@ -151,6 +176,7 @@ extern "C" int disyolo_pack_weights(const float* w_hwio, void* w_fwd, void* w_dg
                                     int cout_pad, void* stream) {
   DY_REQUIRE(w_hwio && (w_fwd || w_dgrad) && ksize > 0 && Cin > 0 && Cout > 0, "pack_weights: bad args");
   DY_REQUIRE(!w_dgrad || cout_pad >= Cout, "pack_weights: cout_pad < Cout");
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_pack_weights(w_hwio, w_fwd, w_dgrad, ksize, Cin, Cout, cout_pad, s); });
   hipStream_t s = (hipStream_t)stream;
   const int taps = ksize * ksize, K = taps * Cin;
   if (w_fwd) {
@@ -173,11 +199,30 @@ extern "C" int disyolo_adam_step(float* w, const float* grad, float* m, float* v
                                  float beta1, float beta2, float eps, float l2, int64_t t, float grad_scale,
                                  void* stream) {
   DY_REQUIRE(w && grad && m && v && n > 0 && t >= 1 && n_decay >= 0 && n_decay <= n, "adam: bad args");
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_adam_step(w, grad, m, v, n, n_decay, lr, beta1, beta2, eps, l2, t, grad_scale, s); });
   const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
   int grid = ceil_div(n, 256);
   if (grid > 256 * 16) grid = 256 * 16;
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, grad, m, v, n, n_decay,
                      (float)lr_t, beta1, beta2, eps, l2, grad_scale);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+extern "C" int disyolo_adam_step_dev(float* w, const float* grad, float* m, float* v, int64_t n, int64_t n_decay,
+                                     float lr, float beta1, float beta2, float eps, float l2, int64_t* step_counter,
+                                     float grad_scale, void* stream) {
+  DY_REQUIRE(w && grad && m && v && step_counter && n > 0 && n_decay >= 0 && n_decay <= n, "adam_dev: bad args");
+  DY_RECORD_OR_RUN([=](void* s) {
+    return disyolo_adam_step_dev(w, grad, m, v, n, n_decay, lr, beta1, beta2, eps, l2, step_counter, grad_scale, s);
+  });
+  int grid = ceil_div(n, 256);
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(grid), dim3(256), 0, s, w, grad, m, v, n, n_decay, lr, beta1, beta2, eps, l2,
+                     grad_scale, (const int64_t*)step_counter);
+  DY_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(64), 0, s, step_counter);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }
@@ -191,6 +236,7 @@ extern "C" int disyolo_l2_loss(const float* w, int64_t n, float l2, float* out, 
     disyolo_set_error("l2_loss: workspace too small");
     return DISYOLO_E_WORKSPACE;
   }
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_l2_loss(w, n, l2, out, workspace, workspace_bytes, s); });
   hipStream_t s = (hipStream_t)stream;
   int nb = ceil_div(n, 256 * 8);
   if (nb > 1024) nb = 1024;

@@ -81,6 +81,15 @@ _SIGS = {
     "disyolo_psroi_assemble": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 3),
     "disyolo_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int64] + [C.c_float] * 5 + [C.c_int64, C.c_float,
                                                                                              C.c_void_p]),
+    "disyolo_adam_step_dev": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int64] + [C.c_float] * 5 + [C.c_void_p, C.c_float,
+                                                                                                 C.c_void_p]),
+    "disyolo_add_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "disyolo_cmdlist_create": (C.c_void_p, []),
+    "disyolo_cmdlist_destroy": (None, [C.c_void_p]),
+    "disyolo_cmdlist_begin": (C.c_int, [C.c_void_p]),
+    "disyolo_cmdlist_end": (C.c_int, []),
+    "disyolo_cmdlist_size": (C.c_int, [C.c_void_p]),
+    "disyolo_cmdlist_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "disyolo_l2_workspace": (C.c_size_t, [C.c_int64]),
     "disyolo_l2_loss": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
@@ -125,16 +134,55 @@ def _need(t: torch.Tensor, dtype, name: str) -> None:
 
 
 class Workspace:
-    """Grow-only device scratch buffer handed to the kernels that need one."""
+    """Grow-only device scratch buffer handed to the kernels that need one.  Once a command
+    list has captured its address it is frozen: a later request that does not fit raises
+    instead of silently moving the buffer."""
 
     def __init__(self, device):
         self.device = device
         self.buf = torch.empty(1 << 20, dtype=torch.uint8, device=device)
+        self.frozen = False
 
     def get(self, nbytes: int) -> torch.Tensor:
         if self.buf.numel() < nbytes:
+            if self.frozen:
+                raise DisyoloError("workspace of %d bytes is frozen by a recorded command list; %d requested"
+                                   % (self.buf.numel(), nbytes))
             self.buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
         return self.buf
+
+
+class CmdList:
+    """Recorded sequence of kernel-library calls replayed by one C call (csrc/runtime.hip)."""
+
+    def __init__(self):
+        self.h = load().disyolo_cmdlist_create()
+        self.keep = []           # tensors / descriptors referenced by the recorded commands
+
+    def __del__(self):
+        try:
+            if self.h:
+                load().disyolo_cmdlist_destroy(self.h)
+        except Exception:
+            pass
+
+    def __enter__(self):
+        global TIMER
+        if TIMER is not None:
+            raise DisyoloError("cannot record a command list while the kernel timer is active")
+        _check(load().disyolo_cmdlist_begin(self.h), "cmdlist_begin")
+        return self
+
+    def __exit__(self, *exc):
+        _check(load().disyolo_cmdlist_end(), "cmdlist_end")
+        return False
+
+    def size(self) -> int:
+        return load().disyolo_cmdlist_size(self.h)
+
+    def run(self, first: int = 0, last: Optional[int] = None) -> None:
+        last = self.size() if last is None else last
+        _check(load().disyolo_cmdlist_run(self.h, first, last, _stream()), "cmdlist_run")
 
 
 def same_pads(size: int, k: int, s: int):
@@ -353,6 +401,15 @@ def psroi_assemble(score, detections, B, max_det, map_size, k, masks, keep) -> N
 def adam_step(w, grad, m, v, n, n_decay, lr, b1, b2, eps, l2, t, grad_scale=1.0) -> None:
     _check(load().disyolo_adam_step(_p(w), _p(grad), _p(m), _p(v), n, n_decay, lr, b1, b2, eps, l2, t, grad_scale,
                                     _stream()), "adam_step")
+
+
+def adam_step_dev(w, grad, m, v, n, n_decay, lr, b1, b2, eps, l2, step_counter, grad_scale=1.0) -> None:
+    _check(load().disyolo_adam_step_dev(_p(w), _p(grad), _p(m), _p(v), n, n_decay, lr, b1, b2, eps, l2,
+                                        _p(step_counter), grad_scale, _stream()), "adam_step_dev")
+
+
+def add_bf16(src, dst, accumulate: bool) -> None:
+    _check(load().disyolo_add_bf16(_p(src), _p(dst), src.numel(), int(accumulate), _stream()), "add_bf16")
 
 
 def l2_loss(w, n, l2, out, ws: Workspace) -> None:

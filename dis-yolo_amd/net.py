@@ -145,9 +145,11 @@ class YOLONet(object):
         self.lock = dict(lock) if lock is not None else {i: (stage == 1 and i <= 52) for i in range(1, 83)}
         self.layers = build_topology(self.num_class, self.k)
         self.by_idx = {l.idx: l for l in self.layers}
-        self.step_count = 0
         self.learning_rate = cfg.LEARNING_RATE
         self.dp = None  # set by enable_data_parallel
+        self._prog = None       # recorded command list of one training step
+        self._prog_marks = []   # [(command index, layer)] all-reduce trigger points
+        self._graph = None      # hipGraph of the recorded step (single GPU)
         self._init_params(seed, xavier_locked)
         self._plan(self.batchsize, self.image_size)
 
@@ -172,6 +174,7 @@ class YOLONet(object):
         self.grad_arena = torch.zeros(n, dtype=F32, device=dev)
         self.adam_m = torch.zeros(n, dtype=F32, device=dev)
         self.adam_v = torch.zeros(n, dtype=F32, device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)   # Adam's t, device resident
         self.arena_slices: Dict[str, Tuple[int, int]] = {}
         off_d, off_n = 0, n_decay
         self.params: Dict[str, torch.Tensor] = {}
@@ -554,11 +557,8 @@ class YOLONet(object):
                 if l.shortcut is not None:
                     sc = self.by_idx[l.shortcut]
                     if sc.grad is not None:
-                        if sc.grad_set:
-                            sc.grad.add_(l.grad)
-                        else:
-                            sc.grad.copy_(l.grad)
-                            sc.grad_set = True
+                        L.add_bf16(l.grad, sc.grad, accumulate=sc.grad_set)
+                        sc.grad_set = True
             if l.idx == 1:
                 L.conv_first_wgrad(self.images, l.dx, l.dw, self.ws)
             else:
@@ -575,24 +575,89 @@ class YOLONet(object):
             if on_layer_done is not None:
                 on_layer_done(l)
 
+    @property
+    def step_count(self) -> int:
+        return int(self.step_dev.item())
+
     def optimizer_step(self, grad_scale: float = 1.0) -> None:
         """tf.train.AdamOptimizer(1e-4).minimize (train_yolo3_mask.py:55) over the arena; the
-        l2 regulariser's gradient (l2*w) is folded in for weights and biases."""
-        self.step_count += 1
+        l2 regulariser's gradient (l2*w) is folded in for weights and biases.  The step count
+        lives on the device so the whole step can be replayed without host state."""
         if self.n_params:
-            L.adam_step(self.arena, self.grad_arena, self.adam_m, self.adam_v, self.n_params, self.n_decay,
-                        self.learning_rate, cfg.ADAM_BETA1, cfg.ADAM_BETA2, cfg.ADAM_EPSILON, self.l2,
-                        self.step_count, grad_scale)
+            L.adam_step_dev(self.arena, self.grad_arena, self.adam_m, self.adam_v, self.n_params, self.n_decay,
+                            self.learning_rate, cfg.ADAM_BETA1, cfg.ADAM_BETA2, cfg.ADAM_EPSILON, self.l2,
+                            self.step_dev, grad_scale)
         for l in self.layers:
             if not l.lock and l.idx > 1:
                 L.pack_weights(l.w, l.wp, l.wdg, l.k, l.cin, l.cout, l.cout_pad)
 
     def total_loss(self) -> torch.Tensor:
         """conf + class + coord + mask + l2 term as a device scalar (tf.losses.get_total_loss,
-        yolo/yolo3_net_pos.py:61).  Valid after compute_losses()."""
-        if self.n_decay:
+        yolo/yolo3_net_pos.py:61).  Valid after compute_losses(); the l2 term is evaluated on
+        the current weights (inside a recorded step: the pre-update weights, like TF)."""
+        if self.n_decay and self._prog is None:
             L.l2_loss(self.arena, self.n_decay, self.l2, self.reg_loss, self.ws)
         return self.losses[7] + self.mask_loss[0] + self.reg_loss[0]
+
+    # ---- recorded step: one C call (or one hipGraph launch) per iteration -------------
+    def build_program(self, det_thresh: float = cfg.OBJ_THRESHOLD, graph: bool = False) -> None:
+        """Record forward + losses + backward + Adam + re-pack into a command list
+        (csrc/runtime.hip).  With data parallelism the list is cut at the gradient-bucket
+        boundaries so the RCCL all-reduces are issued between segments."""
+        if not self.training:
+            raise L.DisyoloError("build_program on a YOLONet built with training=False")
+        prog = L.CmdList()
+        marks = []
+        with prog:
+            self.compute_losses(det_thresh)
+            if self.n_decay:
+                L.l2_loss(self.arena, self.n_decay, self.l2, self.reg_loss, self.ws)
+            if self.dp is not None:
+                triggers = self.dp.by_trigger
+                self.backward(lambda l: marks.append((prog.size(), l)) if l.idx in triggers else None)
+            else:
+                self.backward()
+            self._bwd_end = prog.size()
+            self.optimizer_step(1.0 / self.dp.world_size if self.dp is not None else 1.0)
+        self.ws.frozen = True
+        self._prog, self._prog_marks = prog, marks
+        if graph:
+            if self.dp is not None:
+                raise L.DisyoloError("hipGraph replay is only wired for the single-GPU step")
+            # one warm-up replay outside capture (first-launch module loads are not capturable),
+            # with every piece of training state saved and restored around it
+            state = [self.arena, self.adam_m, self.adam_v, self.step_dev] + \
+                    [t for l in self.layers if l.kind != "lin" for t in (l.mm, l.mv)]
+            saved = [t.clone() for t in state]
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                prog.run()
+            torch.cuda.current_stream().wait_stream(side)
+            for t, v in zip(state, saved):
+                t.copy_(v)
+            self.refresh_weights()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                prog.run()
+            self._graph = g
+
+    def run_program(self) -> None:
+        if self._graph is not None:
+            self._graph.replay()
+            return
+        if self.dp is None:
+            self._prog.run()
+            return
+        self.dp.begin_step()
+        pos = 0
+        for idx, layer in self._prog_marks:
+            self._prog.run(pos, idx)
+            self.dp.on_layer_done(layer)
+            pos = idx
+        self._prog.run(pos, self._bwd_end)
+        self.dp.finish()
+        self._prog.run(self._bwd_end, None)
 
     def train_step(self, batch: Optional[Dict] = None, det_thresh: float = cfg.OBJ_THRESHOLD,
                    want_loss: bool = True):
@@ -601,6 +666,9 @@ class YOLONet(object):
             raise L.DisyoloError("train_step on a YOLONet built with training=False")
         if batch is not None:
             self.set_batch(batch)
+        if self._prog is not None:
+            self.run_program()
+            return self.total_loss() if want_loss else None
         self.compute_losses(det_thresh)
         loss = self.total_loss() if want_loss else None   # loss of the pre-update weights, like TF
         if self.dp is not None:

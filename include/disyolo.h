@@ -193,10 +193,32 @@ int disyolo_psroi_assemble(const float* score, const float* detections, int B, i
 int disyolo_adam_step(float* w, const float* grad, float* m, float* v, int64_t n, int64_t n_decay,
                       float lr, float beta1, float beta2, float eps, float l2, int64_t t,
                       float grad_scale, void* stream);
+/* same with the step count kept in device memory: uses t = *step_counter + 1 and then
+ * increments the counter (nothing about the step lives on the host: replayable) */
+int disyolo_adam_step_dev(float* w, const float* grad, float* m, float* v, int64_t n,
+                          int64_t n_decay, float lr, float beta1, float beta2, float eps, float l2,
+                          int64_t* step_counter, float grad_scale, void* stream);
 /* 0.5*l2*sum(w[0:n]^2) -> out f32[1] (only needed when the loss value is logged) */
 size_t disyolo_l2_workspace(int64_t n);
 int disyolo_l2_loss(const float* w, int64_t n, float l2, float* out, void* workspace,
                     size_t workspace_bytes, void* stream);
+
+/* dst (+)= src over n bf16 elements (n % 8 == 0): gradient accumulation at the residual
+ * shortcuts (yolo/yolo3_net_pos.py:150) */
+int disyolo_add_bf16(const void* src, void* dst, int64_t n, int accumulate, void* stream);
+
+/* ---- command lists: the native step executor ----
+ * Between cmdlist_begin and cmdlist_end every launch entry point above, called from the
+ * recording thread, appends itself to the list (arguments captured by value; device buffers
+ * and workspaces must outlive the list) instead of launching.  cmdlist_run replays commands
+ * [first,last) on `stream` in one call -- the replacement for tf.Session.run's executor on
+ * this path (train_yolo3_mask.py:216), and capturable into a hipGraph. */
+void* disyolo_cmdlist_create(void);
+void disyolo_cmdlist_destroy(void* list);
+int disyolo_cmdlist_begin(void* list);
+int disyolo_cmdlist_end(void);
+int disyolo_cmdlist_size(void* list);
+int disyolo_cmdlist_run(void* list, int first, int last, void* stream);
 
 #ifdef __cplusplus
 }

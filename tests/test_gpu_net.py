@@ -224,3 +224,27 @@ def test_adam_three_step_trace(dev):
         wr, mr, vr = O.adam_tf_step(wr, gr, mr, vr, t)
     torch.cuda.synchronize()
     np.testing.assert_allclose(w.cpu().double().numpy(), wr.numpy(), rtol=1.2e-7, atol=0)  # 1 f32 ulp
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_recorded_step_is_bitwise_identical_to_eager(dev, graph):
+    """The command-list executor (and its hipGraph capture) replays exactly the launches of the
+    per-call path; all reductions are deterministic, so three steps must agree bit for bit."""
+    B, S = 2, 64
+    b = O.synthetic_batch(B, S, seed=21)
+    nets = [make_net(dev, True, 1, B=B, S=S, seed=4) for _ in range(2)]
+    nets[1].load_state_dict(nets[0].state_dict())      # make_net draws the head biases from the global RNG
+    for n in nets:
+        n.set_batch(b)
+    nets[1].build_program(det_thresh=0.1, graph=graph)
+    losses = [[], []]
+    for _ in range(3):
+        losses[0].append(float(nets[0].train_step(None, det_thresh=0.1).cpu()))
+        losses[1].append(float(nets[1].train_step(None).cpu()))
+    torch.cuda.synchronize()
+    assert losses[0] == losses[1]
+    assert torch.equal(nets[0].arena, nets[1].arena)
+    assert torch.equal(nets[0].adam_v, nets[1].adam_v)
+    assert nets[0].step_count == nets[1].step_count == 3
+    for name in nets[0].params:
+        assert torch.equal(nets[0].params[name], nets[1].params[name]), name
