@@ -1,0 +1,185 @@
+"""Hand-derived known answers pinning the CPU oracle's restatement of the reference
+semantics.  TensorFlow 1.x is not runnable here, so these
+are derived by hand from the reference source and TF's documented op semantics."""
+import math
+
+import numpy as np
+import torch
+
+import disyolo_oracle as O
+
+
+def test_same_padding_is_asymmetric_for_stride2_even():
+    # B1: k=3, s=2, even size: pad (0 before, 1 after); s=1: 1 each side; odd size s=2: 1/1
+    assert O.same_pads(576, 3, 2) == (288, 0, 1)
+    assert O.same_pads(576, 3, 1) == (576, 1, 1)
+    assert O.same_pads(17, 3, 2) == (9, 1, 1)
+    assert O.same_pads(72, 1, 1) == (72, 0, 0)
+    # a one-hot input shows where the window sits: with pad_before=0 output (0,0) sees input rows 0..2
+    x = torch.zeros(1, 4, 4, 1)
+    x[0, 0, 0, 0] = 1.0
+    w = torch.arange(9, dtype=torch.float32).reshape(3, 3, 1, 1)
+    y = O.conv2d_same(x, w, 2)
+    assert y.shape == (1, 2, 2, 1)
+    assert float(y[0, 0, 0, 0]) == 0.0      # tap (0,0) hits the pixel: no leading pad
+    x2 = torch.zeros(1, 4, 4, 1)
+    x2[0, 3, 3, 0] = 1.0
+    y2 = O.conv2d_same(x2, w, 2)
+    assert float(y2[0, 1, 1, 0]) == 4.0     # pixel (3,3) is tap (1,1) of the window starting at (2,2)
+
+
+def test_bin_edges_of_the_position_sensitive_assembly():
+    # x1=0,x2=9 -> 0,3,6,9 ; x1=2,x2=9 -> w/3 = 2.333 -> 2,4,7,9
+    assert O.kmask_edges(0, 9) == [0, 3, 6, 9]
+    assert O.kmask_edges(2, 9) == [2, 4, 7, 9]
+    # half-to-even only bites in round(box*size): 2.5 -> 2, 3.5 -> 4 (tf.round)
+    assert float(np.round(np.float32(2.5))) == 2.0 and float(np.round(np.float32(3.5))) == 4.0
+    m = O.channel_index_map([2, 0, 11, 9], 12)       # y1,x1,y2,x2
+    assert m[1, 0] == -1 and m[2, 0] == 0 and m[4, 2] == 0 and m[5, 3] == 4 and m[10, 8] == 8 and m[11, 8] == -1
+    assert (m[:, 9:] == -1).all()
+    # channel = by*3+bx
+    assert m[2, 3] == 1 and m[5, 0] == 3 and m[8, 6] == 8
+
+
+def test_assembled_mask_is_half_outside_the_box_and_zero_scalar_without_detections():
+    score = torch.randn(1, 12, 12, 9)
+    det = np.zeros((1, 30, 6), np.float32)
+    det[0, 0] = [2 / 12, 0, 11 / 12, 9 / 12, 1, 0.9]
+    boxes, masks = O.val_test(det, score)
+    assert boxes[0].shape == (1, 6) and masks[0].shape == (1, 12, 12)
+    assert masks[0][0, 0, 0] == 0.5 and masks[0][0, 11, 11] == 0.5
+    idx = O.channel_index_map([2, 0, 11, 9], 12)
+    y, x = 5, 4
+    assert abs(masks[0][0, y, x] - torch.sigmoid(score[0, y, x, idx[y, x]]).item()) < 1e-6
+    boxes, masks = O.val_test(np.zeros((1, 30, 6), np.float32), score)
+    assert boxes[0].shape == (0, 6) and np.ndim(masks[0]) == 0 and masks[0] == 0.0
+    # degenerate (zero-height after rounding) rows are dropped like the zero padding
+    det[0, 1] = [0.5, 0.1, 0.5, 0.9, 0, 0.8]
+    boxes, _ = O.val_test(det, score)
+    assert boxes[0].shape == (1, 6)
+
+
+def test_nms_on_hand_placed_boxes():
+    boxes = np.array([[0.0, 0.0, 0.4, 0.4],      # A  score .9
+                      [0.05, 0.05, 0.45, 0.45],  # B  IoU(A,B) = .1225/.1975 = .62 -> suppressed
+                      [0.5, 0.5, 0.9, 0.9],      # C  disjoint
+                      [0.0, 0.3, 0.4, 0.7],      # D  IoU(A,D) = .04/.28 = .143 -> kept
+                      [0.3, 0.3, 0.3, 0.8]],     # E  zero area -> IoU 0 with everything -> kept
+                     np.float32)
+    scores = np.array([0.9, 0.8, 0.7, 0.6, 0.5], np.float32)
+    assert O.non_max_suppression(boxes, scores, 30, 0.3) == [0, 2, 3, 4]
+    assert O.non_max_suppression(boxes, scores, 2, 0.3) == [0, 2]
+    # suppression is strict (> threshold): IoU exactly 1/3 survives a 1/3 threshold
+    b2 = np.array([[0, 0, 1, 1], [0, 0.5, 1, 1.5]], np.float32)
+    assert abs(O._tf_iou(b2[0], b2[1]) - 1.0 / 3.0) < 1e-6
+    assert O.non_max_suppression(b2, np.array([0.9, 0.8], np.float32), 30, 0.34) == [0, 1]
+    assert O.non_max_suppression(b2, np.array([0.9, 0.8], np.float32), 30, 0.33) == [0]
+    # ties: the lower index is visited first
+    assert O.non_max_suppression(b2, np.array([0.8, 0.8], np.float32), 30, 0.1) == [0]
+
+
+def _toy_predictions(S=64):
+    g = [S // 8, S // 16, S // 32]
+    return [torch.zeros(1, n, n, 3, 8) for n in g]
+
+
+def test_filter_detections_order_clip_and_padding():
+    yolos = _toy_predictions()
+    # one confident box per scale, different classes; zero logits elsewhere give score .5*1/3 < .25
+    yolos[0][0, 2, 3, 1, 4] = 4.0
+    yolos[0][0, 2, 3, 1, 5] = 6.0
+    yolos[2][0, 1, 0, 2, 4] = 6.0
+    yolos[2][0, 1, 0, 2, 7] = 8.0
+    pred = O.interpret_output(yolos)
+    det = O.filter_detections(pred[2], pred[3], pred[5], np.array([[0, 0, 1, 1]], np.float32), 0.25)
+    assert det.shape == (1, 30, 6)
+    assert (det[0, 2:] == 0).all()
+    assert det[0, 0, 4] == 2 and det[0, 1, 4] == 0 and det[0, 0, 5] > det[0, 1, 5]
+    # box of the first-scale hit: centre ((3+.5)/8, (2+.5)/8), anchor 1 = (62,58)/64
+    y1, x1, y2, x2 = det[0, 1, :4]
+    # -> x in [.4375 -/+ .484], y in [.3125 -/+ .453]: the low edges are clipped to the window at 0
+    assert x1 == 0.0 and y1 == 0.0
+    assert abs(x2 - (3.5 / 8 + 62 / 128)) < 1e-6 and abs(y2 - (2.5 / 8 + 58 / 128)) < 1e-6
+    # boxes are clipped to the window BEFORE the threshold/NMS (B10)
+    det2 = O.filter_detections(pred[2], pred[3], pred[5], np.array([[0.25, 0.25, 0.75, 0.75]], np.float32), 0.25)
+    assert det2[0, :2, :4].min() >= 0.25 and det2[0, :2, :4].max() <= 0.75
+
+
+def test_yolo_loss_scalars_on_a_one_object_target():
+    S = 64
+    yolos = _toy_predictions(S)
+    labels = [torch.zeros_like(y) for y in yolos]
+    # one object on the 8-grid, cell (y=2,x=3), anchor 0 = (31,23): box centre (3.5/8, 2.5/8), w,h = anchor/S
+    w, h = 31.0 / S, 23.0 / S
+    labels[0][0, 2, 3, 0, :4] = torch.tensor([3.5 / 8, 2.5 / 8, w, h])
+    labels[0][0, 2, 3, 0, 4] = 1.0
+    labels[0][0, 2, 3, 0, 6] = 1.0                        # class 1
+    tb = torch.zeros(1, 1, 1, 1, 20, 5)
+    tb[0, 0, 0, 0, 0] = torch.tensor([3.5 / 8, 2.5 / 8, w, h, 1.0])
+    pred = O.interpret_output(yolos)
+    L = O.loss_yolo(pred, tb, labels)
+    ln2 = math.log(2.0)
+    # zero logits: sigmoid CE = ln2 everywhere; object term = 2*ln2
+    assert abs(float(L["obj"]) - 2 * ln2) < 1e-5
+    # the object's own prediction (sigmoid(0)=.5 -> exact centre, exp(0)*anchor -> exact size) has IoU 1
+    # with the GT and is ignored... but it is the object cell; every other cell with best IoU < .5 counts
+    ncell = 3 * (8 * 8 + 4 * 4 + 2 * 2)
+    noobj = float(L["noobj"]) / ln2
+    assert abs(noobj - round(noobj)) < 1e-3 and ncell - 8 <= round(noobj) <= ncell - 1
+    assert abs(float(L["class"]) - math.log(3.0)) < 1e-5
+    # xy: sigmoid(0) = .5 == true offset -> 0;  wh: t=0 == log(wh*S/anchor) = 0 -> 0
+    assert abs(float(L["xy"])) < 1e-9 and abs(float(L["wh"])) < 1e-9
+    # move the target centre by a quarter cell: xy loss = (0.25^2) * (2 - w*h)^2
+    labels[0][0, 2, 3, 0, 0] = 3.75 / 8
+    L2 = O.loss_yolo(pred, tb, labels)
+    assert abs(float(L2["xy"]) - 0.0625 * (2 - w * h) ** 2) < 1e-6
+
+
+def test_tf_form_adam_three_step_trace():
+    # B17: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); eps OUTSIDE the bias-corrected sqrt
+    p, m, v = torch.tensor([1.0], dtype=torch.float64), torch.zeros(1, dtype=torch.float64), torch.zeros(1, dtype=torch.float64)
+    g = torch.tensor([0.5], dtype=torch.float64)
+    p1, m1, v1 = O.adam_tf_step(p, g, m, v, 1)
+    lr1 = 1e-4 * math.sqrt(1 - 0.999) / (1 - 0.9)
+    assert abs(float(m1) - 0.05) < 1e-15 and abs(float(v1) - 0.00025) < 1e-15
+    assert abs(float(p1) - (1.0 - lr1 * 0.05 / (math.sqrt(0.00025) + 1e-8))) < 1e-15
+    p2, m2, v2 = O.adam_tf_step(p1, g, m1, v1, 2)
+    lr2 = 1e-4 * math.sqrt(1 - 0.999 ** 2) / (1 - 0.9 ** 2)
+    assert abs(float(p2) - (float(p1) - lr2 * float(m2) / (math.sqrt(float(v2)) + 1e-8))) < 1e-15
+    # with constant gradients the step is ~lr in magnitude from the first iteration on
+    assert abs((float(p) - float(p1)) - 1e-4) < 1e-8
+
+
+def test_batch_norm_uses_population_variance_and_decay_997():
+    x = torch.tensor([[[[1.0], [3.0]]]])                  # 2 samples: mean 2, population var 1
+    params = {O._name(1, "BatchNorm/gamma"): torch.ones(1), O._name(1, "BatchNorm/beta"): torch.zeros(1),
+              O._name(1, "BatchNorm/moving_mean"): torch.zeros(1), O._name(1, "BatchNorm/moving_variance"): torch.ones(1)}
+    upd = {}
+    y = O.batch_norm(x, params, 1, False, True, upd)
+    assert torch.allclose(y.flatten(), torch.tensor([-1.0, 1.0]) / math.sqrt(1 + 1e-5))
+    assert abs(float(upd[O._name(1, "BatchNorm/moving_mean")]) - 0.003 * 2.0) < 1e-7
+    assert abs(float(upd[O._name(1, "BatchNorm/moving_variance")]) - (0.997 + 0.003 * 1.0)) < 1e-7
+    # lock=True: moving statistics even when is_training (B5)
+    y2 = O.batch_norm(x, params, 1, True, True, {})
+    assert torch.allclose(y2, x / math.sqrt(1 + 1e-5))
+
+
+def test_mask_loss_selection_and_value():
+    S, Sm = 24, 12
+    score = torch.zeros(1, Sm, Sm, 9)
+    tb = np.zeros((1, 1, 1, 1, 20, 5), np.float32)
+    tb[0, 0, 0, 0, 0] = [0.5, 0.5, 0.5, 0.5, 0]           # GT box 0.25..0.75
+    tm = np.zeros((1, 20, S, S), bool)
+    tm[0, 0, 6:18, 6:18] = True
+    det = np.zeros((1, 30, 6), np.float32)
+    det[0, 0] = [0.25, 0.25, 0.75, 0.75, 0, 0.9]           # IoU 1   -> positive
+    det[0, 1] = [0.0, 0.0, 0.3, 0.3, 0, 0.8]               # IoU tiny -> negative
+    rois, assign, rows = O.select_mask_rois(det[0], tb[0, 0, 0, 0])
+    assert len(rois) == 2 and list(assign) == [0, 0] and list(rows) == [0]   # detection + the GT box itself
+    L = O.loss_mask(det, score, tb, tm)
+    # zero logits -> BCE = ln2 on every pixel of each RoI -> mean = ln2 ; x5 ; /B
+    assert abs(float(L) - 5.0 * math.log(2.0)) < 1e-6
+    # no positive RoI -> 0 (yolo/yolo3_net_pos.py:855)
+    det0 = np.zeros((1, 30, 6), np.float32)
+    tb0 = np.zeros_like(tb)
+    assert float(O.loss_mask(det0, score, tb0, tm)) == 0.0

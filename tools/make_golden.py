@@ -1,0 +1,96 @@
+"""Generate the golden fixtures under tests/golden/ by importing the reference's own
+importable modules (yolo/config.py, utils/voc_eval_mask.py) from /root/reference.
+Run in the build container only (the reference never travels to the GPU box):
+
+    python tools/make_golden.py
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+sys.path.insert(0, REF)
+
+
+def config_fixture():
+    import yolo.config as c
+    d = {}
+    for k in sorted(c.__dict__):
+        if k[0].isupper() and k not in ("MODEL_PATH", "DATASET", "OUTPUT_DIR", "WEIGHTS_FILE"):
+            v = getattr(c, k)
+            d[k] = v.tolist() if isinstance(v, np.ndarray) else v
+    with open(os.path.join(OUT, "config.json"), "w") as f:
+        json.dump(d, f, indent=1, sort_keys=True)
+
+
+def voc_fixture():
+    from utils.voc_eval_mask import voc_eval, voc_ap, compute_overlaps_masks
+    rng = np.random.RandomState(7)
+    H = W = 24
+    cases = []
+    for case in range(6):
+        nimg = rng.randint(1, 4)
+        names = ["img%d" % i for i in range(nimg)]
+        recs, gts = {}, {}
+        for n in names:
+            objs = []
+            for _ in range(rng.randint(0, 4)):
+                m = np.zeros((H, W), np.uint8)
+                y, x = rng.randint(0, H - 8), rng.randint(0, W - 8)
+                h, w = rng.randint(3, 8), rng.randint(3, 8)
+                m[y:y + h, x:x + w] = 1
+                objs.append({"classid": int(rng.randint(0, 2)), "mask": m, "difficult": int(rng.rand() < 0.15)})
+            recs[n] = objs
+        dets = []
+        for n in names:
+            for o in recs[n]:
+                if rng.rand() < 0.75:
+                    m = np.roll(o["mask"], rng.randint(-2, 3), axis=rng.randint(0, 2))
+                    dets.append({"imageid": n, "score": float(np.round(rng.rand(), 3)), "mask": m, "classid": o["classid"]})
+            for _ in range(rng.randint(0, 3)):
+                m = np.zeros((H, W), np.uint8)
+                y, x = rng.randint(0, H - 6), rng.randint(0, W - 6)
+                m[y:y + 5, x:x + 5] = 1
+                dets.append({"imageid": n, "score": float(np.round(rng.rand(), 3)), "mask": m,
+                             "classid": int(rng.randint(0, 2))})
+        with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+            f.write("\n".join(names) + "\n")
+            setfile = f.name
+        results = {}
+        for cid in (0, 1):
+            for use07 in (False, True):
+                detfile = [d for d in dets if d["classid"] == cid]
+                r = voc_eval(detfile, recs, setfile, cid, ovthresh=0.5, use_07_metric=use07)
+                results["%d_%d" % (cid, int(use07))] = [float(np.asarray(v)) for v in r]
+        os.unlink(setfile)
+        cases.append({"names": names,
+                      "recs": {n: [{"classid": o["classid"], "difficult": o["difficult"], "mask": o["mask"].tolist()}
+                                   for o in recs[n]] for n in names},
+                      "dets": [{"imageid": d["imageid"], "score": d["score"], "classid": d["classid"],
+                                "mask": d["mask"].tolist()} for d in dets],
+                      "results": results})
+    # the survey's hand-checked known answer: 3 detections / 2 GT -> (1.0, 0.6667, 0.8333)
+    ap_cases = []
+    for _ in range(5):
+        n = rng.randint(1, 8)
+        rec = np.sort(rng.rand(n))
+        prec = rng.rand(n)
+        ap_cases.append({"rec": rec.tolist(), "prec": prec.tolist(), "ap": float(voc_ap(rec, prec, False)),
+                         "ap07": float(voc_ap(rec, prec, True))})
+    m1 = (rng.rand(10, 10, 3) > 0.5).astype(np.float32)
+    m2 = (rng.rand(10, 10, 2) > 0.5).astype(np.float32)
+    ov = compute_overlaps_masks(m1, m2)
+    with open(os.path.join(OUT, "voc_eval.json"), "w") as f:
+        json.dump({"cases": cases, "ap_cases": ap_cases,
+                   "overlaps": {"m1": m1.tolist(), "m2": m2.tolist(), "iou": ov.tolist()}}, f)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    config_fixture()
+    voc_fixture()
+    print("golden fixtures written to", OUT)
