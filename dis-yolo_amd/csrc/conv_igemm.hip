@@ -29,35 +29,76 @@ struct ConvParams {
   float* stats;
   int B, H, W, C0, C1, Cin;
   int Ho, Wo, Cout;
-  int ks, stride, pad_t, pad_l, div;
+  int ks, stride, pad_t, pad_l, dmask, dshift;
   int M, K, nk;
+  unsigned bytes0, bytes1, bytesw;
   int tilesM, tilesN;
   int flags;
   float alpha;
 };
 
-// swizzle of the 16-byte chunk index inside a 64-byte LDS row
+// swizzle of the 16-byte chunk index inside one LDS row: 64-byte rows (BK=32) use a 4-entry
+// table on (row>>2)&3, 128-byte rows (BK=64) XOR (row>>1)&7; both make the 16-lane groups of
+// a ds_read_b128 fragment read hit 16 distinct 16-byte bank slots (DESIGN.md "LDS layout")
+template <int BK>
 __device__ __forceinline__ int swz(int row, int chunk) {
-  return chunk ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3);
+  if (BK == 32) return chunk ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3);
+  return chunk ^ ((row >> 1) & 7);
 }
 
-template <int BM, int BN, int WM, int WN>
+// one LDS-DMA: 64 lanes x 16 B, buffer (descriptor + per-lane 32-bit byte offset) -> LDS
+// (wave-uniform base in M0 + lane*16).  Lanes whose offset is past the descriptor's range get
+// zeros written (hardware range check; probed on gfx950 with tools/probe_lds_dma.hip): that is
+// the zero padding of the SAME conv, the ragged M/N edges and the odd taps of the stride-2
+// data gradient, with no branch and no pointer select.  Issued through inline asm so hipcc
+// does not see a pending LDS write and drain vmcnt(0) before every fragment read; completion
+// is tracked by the counted s_waitcnt vmcnt(N) in the main loop (an LDS-DMA has no VGPR
+// destination, so it is register-safe).  Nothing else in this kernel uses M0.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;
+__device__ __forceinline__ void dma16(unsigned voff, i32x4 srd, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+               :
+               : "v"(voff), "s"(srd), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ i32x4 make_srd(const void* base, unsigned bytes) {
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)base);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((size_t)base >> 32)) & 0xffff;
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int ST>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
-  constexpr int T = WM * WN * 64;
+  constexpr int NW = WM * WN;
+  constexpr int T = NW * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 16, NI = WTN / 16;
-  constexpr int NA = (BM * 4 + T - 1) / T;
-  constexpr int NB = (BN * 4 + T - 1) / T;
-  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
+  constexpr int ROWB = BK * 2;        // bytes per LDS row
+  constexpr int CPR = ROWB / 16;      // 16-byte chunks per row
+  constexpr int SLAB = 1024 * NW;     // bytes one round of DMAs (one per wave) covers
+  constexpr int A_BYTES = (BM * ROWB + SLAB - 1) / SLAB * SLAB;
+  constexpr int B_BYTES = (BN * ROWB + SLAB - 1) / SLAB * SLAB;
+  constexpr int AI = A_BYTES / SLAB, BI = B_BYTES / SLAB;   // DMAs per wave per tile
+  constexpr int LPT = AI + BI;
+  constexpr int STB = A_BYTES + B_BYTES;
+  constexpr int PRE = ST - 1;
   static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be a multiple of 16");
+  static_assert(LPT * (PRE > 0 ? PRE - 1 : 0) < 64, "vmcnt immediate is 6 bits");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sA = smem;                 // [2][BM][64 B]
-  char* sB = smem + 2 * A_BYTES;   // [2][BN][64 B]
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a
@@ -72,91 +113,85 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
   const int mt = tile / p.tilesN, nt = tile - mt * p.tilesN;
   const int m0 = mt * BM, n0 = nt * BN;
 
-  // ---- per-thread gather state for the A (pixel) tile ----
-  const int kc = tid & 3;  // 16-byte chunk (8 channels) inside the 32-wide K slice
-  int a_iy0[NA], a_ix0[NA], a_b[NA];
-  bool a_ok[NA];
+  // ---- per-lane gather state.  DMA j of this wave fills LDS bytes
+  //      [(j*NW + wave)*1024 + lane*16, +16) of the tile: row = chunk / CPR, physical chunk =
+  //      chunk % CPR; the lane fetches the LOGICAL chunk that the swizzle maps there.
+  //      a_base = byte offset of (pixel, tap, logical chunk) at channel 0 of the current
+  //      source, or OOB; it only changes when the K cursor moves to the next filter tap.
+  const i32x4 srd0 = make_srd(p.x0, p.bytes0);
+  const i32x4 srd1 = make_srd(p.x1 ? (const void*)p.x1 : (const void*)p.x0, p.x1 ? p.bytes1 : 0u);
+  const i32x4 srdw = make_srd(p.w, p.bytesw);
+  int a_iy0[AI], a_ix0[AI], a_b[AI];
+  unsigned a_kb[AI], a_base[AI], a_base1[AI];
+  bool a_ok[AI];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const int row = (tid >> 2) + i * (T / 4);
+  for (int j = 0; j < AI; ++j) {
+    const int chunk = (j * NW + wave) * 64 + lane;
+    const int row = chunk / CPR, pc = chunk % CPR;
     const int m = m0 + row;
-    a_ok[i] = (row < BM) && (m < p.M);
-    const int mm = a_ok[i] ? m : 0;
+    a_ok[j] = (row < BM) && (m < p.M);
+    const int mm = a_ok[j] ? m : 0;
     const int hw = p.Ho * p.Wo;
     const int b = mm / hw;
     const int rem = mm - b * hw;
     const int yo = rem / p.Wo;
     const int xo = rem - yo * p.Wo;
-    a_b[i] = b;
-    a_iy0[i] = yo * p.stride - p.pad_t;
-    a_ix0[i] = xo * p.stride - p.pad_l;
+    a_b[j] = b;
+    a_iy0[j] = yo * p.stride - p.pad_t;
+    a_ix0[j] = xo * p.stride - p.pad_l;
+    a_kb[j] = swz<BK>(row, pc) * 16;
+    a_base1[j] = OOB;
+    if (p.C1 > 0) {  // fused upsample+concat (1x1 conv: a single tap, computed once)
+      const int H1 = p.H >> 1, W1 = p.W >> 1;
+      a_base1[j] = a_ok[j] ? (unsigned)(((a_b[j] * H1 + (a_iy0[j] >> 1)) * W1 + (a_ix0[j] >> 1)) * p.C1) * 2u + a_kb[j] : OOB;
+    }
   }
-  bool b_ok[NB];
-  const bf16* b_ptr[NB];
+  unsigned b_base[BI];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const int row = (tid >> 2) + i * (T / 4);
+  for (int j = 0; j < BI; ++j) {
+    const int chunk = (j * NW + wave) * 64 + lane;
+    const int row = chunk / CPR, pc = chunk % CPR;
     const int n = n0 + row;
-    b_ok[i] = (row < BN) && (n < p.Cout);
-    b_ptr[i] = p.w + (size_t)(b_ok[i] ? n : 0) * p.K + kc * 8;
+    b_base[j] = ((row < BN) && (n < p.Cout)) ? (unsigned)n * (unsigned)p.K * 2u + swz<BK>(row, pc) * 16 : OOB;
   }
 
-  uint4 ra[NA], rb[NB];
-  int kh = 0, kw = 0, ci0 = 0, k0 = 0;  // wave-uniform K cursor of the tile being loaded
+  int kh = 0, kw = 0, ci0 = 0, k0 = 0;  // wave-uniform K cursor of the next tile to fetch
 
-  auto load_tile = [&]() {
+  auto issue_tile = [&](int stage) {
+    const unsigned sbase = lds0 + stage * STB + wave * 1024;
+    if (ci0 == 0) {  // new filter tap (wave-uniform): refresh the per-lane pixel offsets
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (a_ok[i]) {
-        int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
-        bool ok = true;
-        if (p.div > 1) {
-          ok = ((iy | ix) >= 0) && (iy % p.div == 0) && (ix % p.div == 0);
-          iy /= p.div;
-          ix /= p.div;
-        }
+      for (int j = 0; j < AI; ++j) {
+        int iy = a_iy0[j] + kh, ix = a_ix0[j] + kw;
+        // transposed gather of a stride-2 data gradient: only even taps are real
+        bool ok = a_ok[j] && (((iy | ix) & p.dmask) == 0);
+        iy >>= p.dshift;
+        ix >>= p.dshift;
         ok = ok && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
-        if (ok) {
-          const bf16* src;
-          if (ci0 < p.C0) {
-            src = p.x0 + ((size_t)(a_b[i] * p.H + iy) * p.W + ix) * p.C0 + ci0 + kc * 8;
-          } else {
-            const int H1 = p.H >> 1, W1 = p.W >> 1;
-            src = p.x1 + ((size_t)(a_b[i] * H1 + (iy >> 1)) * W1 + (ix >> 1)) * p.C1 + (ci0 - p.C0) + kc * 8;
-          }
-          v = *reinterpret_cast<const uint4*>(src);
-        }
+        a_base[j] = ok ? (unsigned)(((a_b[j] * p.H + iy) * p.W + ix) * p.C0) * 2u + a_kb[j] : OOB;
       }
-      ra[i] = v;
     }
+    if (ci0 < p.C0) {
+      const unsigned cs2 = ci0 * 2;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (b_ok[i]) v = *reinterpret_cast<const uint4*>(b_ptr[i] + k0);
-      rb[i] = v;
+      for (int j = 0; j < AI; ++j) dma16(a_base[j] + cs2, srd0, sbase + j * SLAB);
+    } else {
+      const unsigned cs2 = (ci0 - p.C0) * 2;
+#pragma unroll
+      for (int j = 0; j < AI; ++j) dma16(a_base1[j] + cs2, srd1, sbase + j * SLAB);
     }
-    // advance the K cursor by one 32-wide slice
-    k0 += 32;
-    ci0 += 32;
+    const unsigned k2 = k0 * 2;
+#pragma unroll
+    for (int j = 0; j < BI; ++j) dma16(b_base[j] + k2, srdw, sbase + A_BYTES + j * SLAB);
+    // advance the K cursor by one BK-wide slice
+    k0 += BK;
+    ci0 += BK;
     if (ci0 >= p.Cin) {
       ci0 = 0;
       if (++kw == p.ks) {
         kw = 0;
         ++kh;
       }
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int row = (tid >> 2) + i * (T / 4);
-      if (row < BM) *reinterpret_cast<uint4*>(sA + buf * A_BYTES + row * 64 + swz(row, kc) * 16) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int row = (tid >> 2) + i * (T / 4);
-      if (row < BN) *reinterpret_cast<uint4*>(sB + buf * B_BYTES + row * 64 + swz(row, kc) * 16) = rb[i];
     }
   };
 
@@ -166,34 +201,52 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_tile();
-  store_tile(0);
-  __syncthreads();
+  // ---- software pipeline: PRE tiles in flight.  Iteration kt: wait until this wave's DMAs
+  //      of tile kt have landed (counted vmcnt leaves the younger tiles in flight), barrier
+  //      (everyone's have, and everyone is done reading the stage refilled next), issue tile
+  //      kt+PRE, then multiply tile kt.
+#pragma unroll
+  for (int s = 0; s < PRE; ++s)
+    if (s < p.nk) issue_tile(s);
 
   const int frow = lane & 15, fchunk = lane >> 4;
   for (int kt = 0; kt < p.nk; ++kt) {
-    const int cur = kt & 1;
-    const bool more = (kt + 1 < p.nk);
-    if (more) load_tile();
-    bf16x8 xf[MI], wf[NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int row = wm * WTM + i * 16 + frow;
-      xf[i] = *reinterpret_cast<const bf16x8*>(sA + cur * A_BYTES + row * 64 + swz(row, fchunk) * 16);
+    if (PRE >= 1 && kt + PRE - 1 < p.nk)
+      wait_vmcnt<LPT*(PRE >= 1 ? PRE - 1 : 0)>();
+    else
+      wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (PRE >= 1) {
+      if (kt + PRE < p.nk) issue_tile((kt + PRE) % ST);
     }
+    const char* sA = smem + (kt % ST) * STB;
+    const char* sB = sA + A_BYTES;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int row = wn * WTN + j * 16 + frow;
-      wf[j] = *reinterpret_cast<const bf16x8*>(sB + cur * B_BYTES + row * 64 + swz(row, fchunk) * 16);
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      bf16x8 xf[MI], wf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = wm * WTM + i * 16 + frow;
+        xf[i] = *reinterpret_cast<const bf16x8*>(sA + row * ROWB + swz<BK>(row, kk * 4 + fchunk) * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int row = wn * WTN + j * 16 + frow;
+        wf[j] = *reinterpret_cast<const bf16x8*>(sB + row * ROWB + swz<BK>(row, kk * 4 + fchunk) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-    if (more) store_tile(cur ^ 1);
-    __syncthreads();
+    if (PRE == 0) {  // single stage: refill only after everyone has consumed the tile
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < p.nk) issue_tile(0);
+    }
   }
+  __syncthreads();  // all fragment reads done before the LDS is reused by the epilogue
 
   // ---- epilogue.  acc[i][j][r]: pixel m0 + wm*WTM + i*16 + (lane&15),
   //      channel n0 + wn*WTN + j*16 + 4*(lane>>4) + r ----
@@ -301,42 +354,72 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
 }
 
 struct TileCfg {
-  int id, bm, bn, threads;
+  int id, bm, bn;
 };
-// id -> (BM, BN, WM, WN)
+// id -> block tile (pixels x channels); the wave grid, K depth and pipeline stages per
+// variant are in dispatch()
 const TileCfg kTiles[] = {
-    {1, 128, 128, 256},  // 2x2 waves, 64x64 per wave
-    {2, 128, 64, 256},   // 2x2 waves, 64x32
-    {3, 64, 128, 256},   // 2x2 waves, 32x64
-    {4, 128, 32, 256},   // 4x1 waves, 32x32
-    {5, 128, 16, 256},   // 4x1 waves, 32x16
-    {6, 64, 64, 256},    // 2x2 waves, 32x32
-    {7, 256, 64, 256},   // 4x1 waves, 64x64
+    {1, 128, 128}, {2, 128, 64}, {3, 64, 128}, {4, 128, 32}, {5, 128, 16}, {6, 64, 64}, {7, 256, 64}, {8, 256, 128},
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK, int ST>
 int launch(const ConvParams& p, hipStream_t s) {
   ConvParams q = p;
   q.tilesM = ceil_div(p.M, BM);
   q.tilesN = ceil_div(p.Cout, BN);
+  q.nk = p.K / BK;
   const int grid = q.tilesM * q.tilesN;
-  size_t lds = 2 * (size_t)(BM + BN) * 64;
+  constexpr int NW = WM * WN, SLAB = 1024 * NW, ROWB = BK * 2;
+  constexpr int A_BYTES = (BM * ROWB + SLAB - 1) / SLAB * SLAB, B_BYTES = (BN * ROWB + SLAB - 1) / SLAB * SLAB;
+  size_t lds = (size_t)ST * (A_BYTES + B_BYTES);
   const size_t red = (size_t)WM * BN * 2 * sizeof(float);
   if (red > lds) lds = red;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(WM * WN * 64), lds, s, q);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, ST>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, ST>), dim3(grid), dim3(NW * 64), lds, s, q);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }
 
+// BK = 64 needs every source's channel count to be a multiple of 64 (a K slice never
+// straddles a filter tap or the concat boundary).  variant: 0 = default pipeline depth,
+// 1 = alternative depth (tuning)
+#define DY_TILE(ID, BM, BN, WM, WN, S64A, S64B, S32A, S32B)                                          \
+  case ID:                                                                                          \
+    if (bk64) return variant ? launch<BM, BN, WM, WN, 64, S64B>(p, s) : launch<BM, BN, WM, WN, 64, S64A>(p, s); \
+    return variant ? launch<BM, BN, WM, WN, 32, S32B>(p, s) : launch<BM, BN, WM, WN, 32, S32A>(p, s);
+int dispatch(int id, bool bk64, int variant, const ConvParams& p, hipStream_t s) {
+  switch (id) {
+    DY_TILE(1, 128, 128, 2, 2, 2, 3, 3, 4)
+    DY_TILE(2, 128, 64, 2, 2, 3, 2, 4, 3)
+    DY_TILE(3, 64, 128, 2, 2, 2, 3, 4, 3)
+    DY_TILE(4, 128, 32, 4, 1, 3, 2, 4, 3)
+    DY_TILE(5, 128, 16, 4, 1, 3, 2, 4, 3)
+    DY_TILE(6, 64, 64, 2, 2, 3, 2, 4, 3)
+    DY_TILE(7, 256, 64, 4, 1, 3, 2, 4, 3)
+    DY_TILE(8, 256, 128, 4, 2, 2, 3, 3, 4)
+    default: disyolo_set_error("conv: unknown tile id %d", id); return DISYOLO_E_ARG;
+  }
+}
+
+// Launcher heuristic, from the per-layer sweep of tools/bench_conv.py on MI355X (B = 8, 576^2;
+// profiles/r01_conv_tile_sweep.txt).  Occupancy beats pipeline depth on these shapes: the
+// 64x128 tile (94 registers, 48 KiB LDS at BK=64 x 2 stages -> 3 blocks per CU) is within a few
+// percent of the best everywhere; the 8-wave 256x128 tile at BK=32 wins where M is huge.
+// Returns id | flags: bit 8 = force BK 32, bit 9 = alternative pipeline depth.
 int pick_tile(const disyolo_conv_desc* d, int M) {
   if (d->tile > 0) return d->tile;
   const int N = d->Cout;
+  const int K = d->ksize * d->ksize * (d->C0 + d->C1);
   if (N <= 16) return 5;
   if (N <= 32) return 4;
   if (N <= 64) return M >= 256 * 256 ? 7 : 2;
-  // N >= 128: prefer 128x128 unless that leaves the 256 CUs under-filled
-  const int t128 = ceil_div(M, 128) * ceil_div(N, 128);
-  if (t128 >= 384) return 1;
+  if (M >= 40000 && K >= 576 && N % 128 == 0) return 8 | 0x100;
+  if (M < 4096) return 3 | 0x200;   // few blocks per CU: the deeper pipeline pays
   return 3;
 }
 
@@ -354,10 +437,13 @@ int validate(const disyolo_conv_desc* d) {
   DY_REQUIRE(d->C1 >= 0 && d->C1 % 32 == 0, "conv: C1=%d must be a multiple of 32", d->C1);
   DY_REQUIRE(d->C1 == 0 || (d->ksize == 1 && d->stride == 1 && d->x1 != nullptr && (d->H % 2 == 0) && (d->W % 2 == 0)),
              "conv: fused upsample+concat needs a 1x1 stride-1 conv with even H,W");
-  DY_REQUIRE(d->in_div >= 1, "conv: in_div must be >= 1");
+  DY_REQUIRE(d->in_div == 1 || d->in_div == 2, "conv: in_div must be 1 or 2");
   DY_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0, "conv: bad sizes");
   DY_REQUIRE((int64_t)d->B * d->Ho * d->Wo < (1LL << 31), "conv: too many output pixels");
   DY_REQUIRE(d->x0 && d->w && d->y, "conv: null tensor pointer");
+  DY_REQUIRE((int64_t)d->B * d->H * d->W * d->C0 * 2 < (1LL << 31) &&
+                 (int64_t)d->Cout * d->ksize * d->ksize * (d->C0 + d->C1) * 2 < (1LL << 31),
+             "conv: a source tensor or the packed weights exceed the 2 GiB the 32-bit gather offsets address");
   return DISYOLO_OK;
 }
 
@@ -366,14 +452,14 @@ int validate(const disyolo_conv_desc* d) {
 extern "C" int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d) {
   if (!d) return DISYOLO_E_ARG;
   const int M = d->B * d->Ho * d->Wo;
-  const int bm = tile_bm(pick_tile(d, M));
+  const int bm = tile_bm(pick_tile(d, M) & 0xff);
   if (bm == 0) return DISYOLO_E_ARG;
   return ceil_div(M, bm);
 }
 
 extern "C" int disyolo_conv2d_tile(const disyolo_conv_desc* d, int* bm, int* bn) {
   if (!d) return DISYOLO_E_ARG;
-  const int id = pick_tile(d, d->B * d->Ho * d->Wo);
+  const int id = pick_tile(d, d->B * d->Ho * d->Wo) & 0xff;
   for (const TileCfg& t : kTiles)
     if (t.id == id) {
       if (bm) *bm = t.bm;
@@ -402,22 +488,21 @@ extern "C" int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream) {
   p.stats = d->stats;
   p.B = d->B; p.H = d->H; p.W = d->W; p.C0 = d->C0; p.C1 = d->C1; p.Cin = d->C0 + d->C1;
   p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
-  p.ks = d->ksize; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.div = d->in_div;
+  p.ks = d->ksize; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+  p.dmask = d->in_div - 1; p.dshift = d->in_div == 2 ? 1 : 0;
   p.M = d->B * d->Ho * d->Wo;
   p.K = d->ksize * d->ksize * p.Cin;
-  p.nk = p.K / 32;
+  p.bytes0 = (unsigned)((size_t)d->B * d->H * d->W * d->C0 * 2);
+  p.bytes1 = (unsigned)((size_t)d->B * (d->H / 2) * (d->W / 2) * d->C1 * 2);
+  p.bytesw = (unsigned)((size_t)d->Cout * p.K * 2);
+  p.nk = 0;
   p.flags = d->flags;
   p.alpha = d->alpha;
   p.tilesM = p.tilesN = 0;
   hipStream_t s = (hipStream_t)stream;
-  switch (pick_tile(d, p.M)) {
-    case 1: return launch<128, 128, 2, 2>(p, s);
-    case 2: return launch<128, 64, 2, 2>(p, s);
-    case 3: return launch<64, 128, 2, 2>(p, s);
-    case 4: return launch<128, 32, 4, 1>(p, s);
-    case 5: return launch<128, 16, 4, 1>(p, s);
-    case 6: return launch<64, 64, 2, 2>(p, s);
-    case 7: return launch<256, 64, 4, 1>(p, s);
-    default: disyolo_set_error("conv: unknown tile id %d", d->tile); return DISYOLO_E_ARG;
-  }
+  // tile field: low byte = tile id (0 = auto); bit 8 forces BK = 32, bit 9 selects the
+  // alternative pipeline depth (tuning / testing)
+  const int sel = pick_tile(d, p.M);
+  const bool bk64 = (d->C0 % 64 == 0) && (d->C1 % 64 == 0) && !(sel & 0x100);
+  return dispatch(sel & 0xff, bk64, (sel >> 9) & 1, p, s);
 }

@@ -51,6 +51,14 @@ CASES = [
     (1, 40, 40, 64, 64, 3, 1, 7),
     (3, 9, 9, 256, 256, 3, 1, 0),
     (1, 16, 16, 1024, 512, 1, 1, 0),
+    (2, 18, 18, 64, 128, 3, 1, 8),         # 256x128 tile, 8 waves
+    (2, 18, 18, 64, 128, 3, 1, 0x101),     # BK forced to 32 on a BK=64-capable shape
+    (2, 18, 18, 64, 128, 3, 1, 0x108),
+    (4, 36, 36, 128, 256, 3, 1, 1),        # 36 K-steps: exercises the steady-state pipeline
+    (4, 36, 36, 128, 256, 3, 1, 8),
+    (1, 12, 12, 32, 32, 3, 1, 6),          # 9 K-steps of BK=32
+    (2, 12, 12, 64, 16, 1, 1, 5),          # nk = 1 (shorter than the pipeline depth)
+    (2, 12, 12, 128, 64, 1, 1, 2),         # nk = 2
 ]
 
 
