@@ -24,125 +24,161 @@ struct WgradParams {
   int ks, stride, pad_t, pad_l;
   int M, K;
   int steps_per_split, steps;
+  unsigned bytes0, bytes1, bytesy;
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;
 
-// 32-byte-unit swizzle inside one LDS row of `units` units
+// 32-byte-unit swizzle inside one LDS row of `units` units: the two 16-lane groups of a
+// 32-lane half of ds_read_b64_tr_b16 (rows 8g..8g+3 and 8g+8..) land on disjoint banks
 __device__ __forceinline__ int swz_u(int row, int u, int units) {
   const int h = (row & 3) | (((row >> 3) & 1) << 2);
   return u ^ (h & (units - 1));
 }
+// LDS-DMA through a buffer descriptor: out-of-range lanes write zeros (see conv_igemm.hip)
+__device__ __forceinline__ void dma16(unsigned voff, i32x4 srd, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+               :
+               : "v"(voff), "s"(srd), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ i32x4 make_srd(const void* base, unsigned bytes) {
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)base);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((size_t)base >> 32)) & 0xffff;
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ uint4 g_zero16;
+__device__ __forceinline__ void dma16_flat(const void* gsrc, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
-template <int BN>
+// Block = 128 K-rows x BN channels, 4 waves (2x2).  Per reduction step the block stages a
+// [32 pixels][128 k] image of the gathered input and a [32 pixels][BN] image of dy with LDS-DMA
+// (ST stages, counted vmcnt, one barrier per step) and multiplies them with transposed LDS reads.
+template <int BN, int ST>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
-  constexpr int BM = 128;  // K-index rows per block
-  constexpr int WM = 2, WN = 2;
+  constexpr int BM = 128;
+  constexpr int WM = 2, WN = 2, NW = 4;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 16, NI = WTN / 16;
-  constexpr int XCH = BM / 8, YCH = BN / 8;          // 16-byte chunks per pixel row
-  constexpr int NX = 32 * XCH / 256, NY = (32 * YCH + 255) / 256;
-  constexpr int XP = BM * 2, YP = BN * 2;            // row pitch in bytes
-  constexpr int X_BYTES = 32 * XP, Y_BYTES = 32 * YP;
+  constexpr int XCH = BM / 8, YCH = BN / 8;  // 16-byte chunks per pixel row
+  constexpr int XP = BM * 2, YP = BN * 2;    // row pitch in bytes
+  constexpr int SLAB = 1024 * NW;
+  constexpr int X_BYTES = 32 * XP;                                      // 8 KiB
+  constexpr int Y_BYTES = (32 * YP + SLAB - 1) / SLAB * SLAB;
+  constexpr int XI = X_BYTES / SLAB, YI = Y_BYTES / SLAB;
+  constexpr int LPT = XI + YI;
+  constexpr int STB = X_BYTES + Y_BYTES;
+  constexpr int PRE = ST - 1;
   static_assert(WTN % 16 == 0, "BN must be a multiple of 32");
 
-  __shared__ __attribute__((aligned(16))) char smem[2 * X_BYTES + 2 * Y_BYTES];
-  char* sX = smem;
-  char* sY = smem + 2 * X_BYTES;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int kt0 = blockIdx.x * BM;  // first K index of this block
   const int n0 = blockIdx.y * BN;
   const int step0 = blockIdx.z * p.steps_per_split;
   int step1 = step0 + p.steps_per_split;
   if (step1 > p.steps) step1 = p.steps;
+  const int nsteps = step1 - step0;
 
-  // ---- X gather state: thread owns NX (pixel-lane, k-chunk) pairs; the k part is fixed
-  int x_pl[NX], x_kh[NX], x_kw[NX], x_ci[NX];
-  bool x_kok[NX];
-  int x_b[NX], x_yo[NX], x_xo[NX];
+  const i32x4 srd0 = make_srd(p.x0, p.bytes0);
+  const i32x4 srd1 = make_srd(p.x1 ? (const void*)p.x1 : (const void*)p.x0, p.x1 ? p.bytes1 : 0u);
+  const i32x4 srdy = make_srd(p.dy, p.bytesy);
+
+  // ---- X gather: DMA j of this wave fills rows (j*NW+wave)*4 .. +3 of the step's image; the
+  //      lane's (tap, channel) is fixed for the block, its pixel advances by 32 per step
+  int x_kh[XI], x_kw[XI], x_ci[XI], x_b[XI], x_yo[XI], x_xo[XI];
+  bool x_kok[XI], x_second[XI];
 #pragma unroll
-  for (int i = 0; i < NX; ++i) {
-    const int c = tid + i * 256;
-    x_pl[i] = c / XCH;
-    const int kk = kt0 + (c % XCH) * 8;
-    x_kok[i] = kk < p.K;
-    const int kq = x_kok[i] ? kk : 0;
+  for (int j = 0; j < XI; ++j) {
+    const int chunk = (j * NW + wave) * 64 + lane;
+    const int row = chunk / XCH, pc = chunk % XCH;
+    const int lc = swz_u(row, pc >> 1, XCH / 2) * 2 + (pc & 1);
+    const int kk = kt0 + lc * 8;
+    x_kok[j] = kk < p.K;
+    const int kq = x_kok[j] ? kk : 0;
     const int tap = kq / p.Cin;
-    x_ci[i] = kq - tap * p.Cin;
-    x_kh[i] = tap / p.ks;
-    x_kw[i] = tap - x_kh[i] * p.ks;
-    const int m = step0 * 32 + x_pl[i];
+    int ci = kq - tap * p.Cin;
+    x_second[j] = ci >= p.C0;
+    x_ci[j] = x_second[j] ? ci - p.C0 : ci;
+    x_kh[j] = tap / p.ks;
+    x_kw[j] = tap - x_kh[j] * p.ks;
+    const int m = step0 * 32 + row;
     const int hw = p.Ho * p.Wo;
     const int b = m / hw;
     const int rem = m - b * hw;
-    x_b[i] = b;
-    x_yo[i] = rem / p.Wo;
-    x_xo[i] = rem - x_yo[i] * p.Wo;
+    x_b[j] = b;
+    x_yo[j] = rem / p.Wo;
+    x_xo[j] = rem - x_yo[j] * p.Wo;
   }
-  uint4 rx[NX], ry[NY];
-  int lstep = step0;  // step being loaded
+  // ---- dy: plain rows of ldy channels
+  unsigned y_off[YI];
+  int y_m[YI];
+  bool y_nok[YI];
+#pragma unroll
+  for (int j = 0; j < YI; ++j) {
+    const int chunk = (j * NW + wave) * 64 + lane;
+    const int row = chunk / YCH, pc = chunk % YCH;
+    const int lc = swz_u(row, pc >> 1, YCH / 2) * 2 + (pc & 1);
+    const int n = n0 + lc * 8;
+    y_nok[j] = (row < 32) && (n < p.ldy);
+    y_m[j] = step0 * 32 + row;
+    y_off[j] = ((unsigned)y_m[j] * (unsigned)p.ldy + (unsigned)n) * 2u;
+  }
 
-  auto load_tiles = [&]() {
+  const bool mixed = (p.C1 > 0) && ((p.C0 & (BM - 1)) != 0);
+  const bool blk_second = (p.C1 > 0) && (kt0 >= p.C0);
+  auto issue_tile = [&](int stage) {
+    const unsigned sbase = lds0 + stage * STB + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (x_kok[i] && x_b[i] < p.B) {
-        const int iy = x_yo[i] * p.stride - p.pad_t + x_kh[i];
-        const int ix = x_xo[i] * p.stride - p.pad_l + x_kw[i];
-        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-          const bf16* src;
-          if (x_ci[i] < p.C0) {
-            src = p.x0 + ((size_t)(x_b[i] * p.H + iy) * p.W + ix) * p.C0 + x_ci[i];
-          } else {
-            const int H1 = p.H >> 1, W1 = p.W >> 1;
-            src = p.x1 + ((size_t)(x_b[i] * H1 + (iy >> 1)) * W1 + (ix >> 1)) * p.C1 + (x_ci[i] - p.C0);
-          }
-          v = *reinterpret_cast<const uint4*>(src);
+    for (int j = 0; j < XI; ++j) {
+      const int iy = x_yo[j] * p.stride - p.pad_t + x_kh[j];
+      const int ix = x_xo[j] * p.stride - p.pad_l + x_kw[j];
+      const bool ok = x_kok[j] && (x_b[j] < p.B) && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
+      unsigned off;
+      if (!x_second[j]) {
+        off = (unsigned)(((x_b[j] * p.H + iy) * p.W + ix) * p.C0 + x_ci[j]) * 2u;
+      } else {
+        const int H1 = p.H >> 1, W1 = p.W >> 1;
+        off = (unsigned)(((x_b[j] * H1 + (iy >> 1)) * W1 + (ix >> 1)) * p.C1 + x_ci[j]) * 2u;
+      }
+      if (!mixed) {
+        // the block's 128 K rows come from one source: one descriptor per block
+        if (blk_second) dma16(ok ? off : OOB, srd1, sbase + j * SLAB);
+        else dma16(ok ? off : OOB, srd0, sbase + j * SLAB);
+      } else {
+        // concat boundary inside the block's K range (C0 not a multiple of 128): per-lane
+        // flat addresses, zeros from a 16-byte zero page
+        const void* src = ok ? (const void*)((const char*)(x_second[j] ? p.x1 : p.x0) + off) : (const void*)&g_zero16;
+        dma16_flat(src, sbase + j * SLAB);
+      }
+      // advance this lane's pixel by 32
+      x_xo[j] += 32;
+      while (x_xo[j] >= p.Wo) {
+        x_xo[j] -= p.Wo;
+        if (++x_yo[j] == p.Ho) {
+          x_yo[j] = 0;
+          ++x_b[j];
         }
       }
-      rx[i] = v;
-      // advance this chunk's pixel by 32
-      x_xo[i] += 32;
-      while (x_xo[i] >= p.Wo) {
-        x_xo[i] -= p.Wo;
-        if (++x_yo[i] == p.Ho) {
-          x_yo[i] = 0;
-          ++x_b[i];
-        }
-      }
     }
 #pragma unroll
-    for (int i = 0; i < NY; ++i) {
-      const int c = tid + i * 256;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (c < 32 * YCH) {
-        const int pl = c / YCH, ch = c % YCH;
-        const int m = lstep * 32 + pl;
-        const int n = n0 + ch * 8;
-        if (m < p.M && n < p.ldy) v = *reinterpret_cast<const uint4*>(p.dy + (size_t)m * p.ldy + n);
-      }
-      ry[i] = v;
-    }
-    ++lstep;
-  };
-  auto store_tiles = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      const int c = tid + i * 256;
-      const int pl = c / XCH, ch = c % XCH;
-      const int off = pl * XP + swz_u(pl, ch >> 1, XCH / 2) * 32 + (ch & 1) * 16;
-      *reinterpret_cast<uint4*>(sX + buf * X_BYTES + off) = rx[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NY; ++i) {
-      const int c = tid + i * 256;
-      if (c < 32 * YCH) {
-        const int pl = c / YCH, ch = c % YCH;
-        const int off = pl * YP + swz_u(pl, ch >> 1, YCH / 2) * 32 + (ch & 1) * 16;
-        *reinterpret_cast<uint4*>(sY + buf * Y_BYTES + off) = ry[i];
-      }
+    for (int j = 0; j < YI; ++j) {
+      dma16((y_nok[j] && y_m[j] < p.M) ? y_off[j] : OOB, srdy, sbase + X_BYTES + j * SLAB);
+      y_m[j] += 32;
+      y_off[j] += 32u * (unsigned)p.ldy * 2u;
     }
   };
 
@@ -152,43 +188,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (step0 < step1) {
-    load_tiles();
-    store_tiles(0);
-  }
-  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < PRE; ++s)
+    if (s < nsteps) issue_tile(s);
 
   // transposed-read addressing (cdna guide T10): inside a 16-lane group, lane 4q+p supplies
   // the address of row q, columns 4p..4p+3 of a 4x16 block and receives column (lane&15).
   const int g = lane >> 4, li = lane & 15, q = li >> 2, pc = li & 3;
-  for (int st = step0; st < step1; ++st) {
-    const int cur = (st - step0) & 1;
-    const bool more = st + 1 < step1;
-    if (more) load_tiles();
+  for (int st = 0; st < nsteps; ++st) {
+    if (PRE >= 1 && st + PRE - 1 < nsteps)
+      wait_vmcnt<LPT*(PRE >= 1 ? PRE - 1 : 0)>();
+    else
+      wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (st + PRE < nsteps) issue_tile((st + PRE) % ST);
+    const char* sX = smem + (st % ST) * STB;
+    const char* sY = sX + X_BYTES;
     bf16x8 af[MI], bfr[NI];
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const int r0 = 8 * g + q, r1 = r0 + 4;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int u = (wm * WTM + i * 16) >> 4;
-      const int r0 = 8 * g + q, r1 = r0 + 4;
-      const char* base = sX + cur * X_BYTES;
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (lds_s16x4*)(base + r0 * XP + swz_u(r0, u, XCH / 2) * 32 + pc * 8));
+          (lds_s16x4*)(sX + r0 * XP + swz_u(r0, u, XCH / 2) * 32 + pc * 8));
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (lds_s16x4*)(base + r1 * XP + swz_u(r1, u, XCH / 2) * 32 + pc * 8));
-      typedef short s16x8 __attribute__((ext_vector_type(8)));
+          (lds_s16x4*)(sX + r1 * XP + swz_u(r1, u, XCH / 2) * 32 + pc * 8));
       const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       af[i] = __builtin_bit_cast(bf16x8, v);
     }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int u = (wn * WTN + j * 16) >> 4;
-      const int r0 = 8 * g + q, r1 = r0 + 4;
-      const char* base = sY + cur * Y_BYTES;
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (lds_s16x4*)(base + r0 * YP + swz_u(r0, u, YCH / 2) * 32 + pc * 8));
+          (lds_s16x4*)(sY + r0 * YP + swz_u(r0, u, YCH / 2) * 32 + pc * 8));
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (lds_s16x4*)(base + r1 * YP + swz_u(r1, u, YCH / 2) * 32 + pc * 8));
-      typedef short s16x8 __attribute__((ext_vector_type(8)));
+          (lds_s16x4*)(sY + r1 * YP + swz_u(r1, u, YCH / 2) * 32 + pc * 8));
       const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       bfr[j] = __builtin_bit_cast(bf16x8, v);
     }
@@ -197,8 +233,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
       for (int j = 0; j < NI; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    if (more) store_tiles(cur ^ 1);
-    __syncthreads();
   }
 
   // D: row (K index) = 4*(lane>>4) + r, col (co) = lane&15
@@ -218,13 +252,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
   }
 }
 
+// out[i] = sum_k slabs[k][i] in a fixed order.  256 threads = 64 outputs x 4 split lanes
+// (lane g sums k = g, g+4, ... with four loads in flight), combined through LDS: short
+// dependent chains even for hundreds of splits of a small matrix.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slabs, float* out, int64_t n, int splits) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * n + i];
-    out[i] = s;
+  __shared__ float sh[4][64];
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + o;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (i < n) {
+    int k = g;
+    for (; k + 12 < splits; k += 16) {
+      a0 += slabs[(size_t)k * n + i];
+      a1 += slabs[(size_t)(k + 4) * n + i];
+      a2 += slabs[(size_t)(k + 8) * n + i];
+      a3 += slabs[(size_t)(k + 12) * n + i];
+    }
+    for (; k < splits; k += 4) a0 += slabs[(size_t)k * n + i];
   }
+  sh[g][o] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (g == 0 && i < n) out[i] = (sh[0][o] + sh[1][o]) + (sh[2][o] + sh[3][o]);
 }
 
 // first layer (Cin = 3): dw[27][Cout] by direct accumulation; each block reduces a pixel
@@ -286,6 +334,8 @@ extern "C" int disyolo_conv2d_wgrad(const disyolo_conv_desc* d, const void* dy, 
   DY_REQUIRE(d->C1 == 0 || (d->ksize == 1 && d->stride == 1 && d->x1), "wgrad: bad fused-concat layer");
   DY_REQUIRE(dy_ld >= d->Cout && dy_ld % 8 == 0, "wgrad: dy_ld must be >= Cout and a multiple of 8");
   DY_REQUIRE(d->in_div == 1, "wgrad: in_div must be 1");
+  DY_REQUIRE((int64_t)d->B * d->H * d->W * d->C0 * 2 < (1LL << 31) && (int64_t)d->B * d->Ho * d->Wo * dy_ld * 2 < (1LL << 31),
+             "wgrad: a source tensor exceeds the 2 GiB the 32-bit gather offsets address");
   if (!workspace || workspace_bytes < disyolo_conv2d_wgrad_workspace(d)) {
     disyolo_set_error("wgrad: workspace too small");
     return DISYOLO_E_WORKSPACE;
@@ -303,23 +353,26 @@ extern "C" int disyolo_conv2d_wgrad(const disyolo_conv_desc* d, const void* dy, 
   p.ks = d->ksize; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
   p.M = d->B * d->Ho * d->Wo;
   p.K = d->ksize * d->ksize * p.Cin;
+  p.bytes0 = (unsigned)((size_t)d->B * d->H * d->W * d->C0 * 2);
+  p.bytes1 = (unsigned)((size_t)d->B * (d->H / 2) * (d->W / 2) * d->C1 * 2);
+  p.bytesy = (unsigned)((size_t)p.M * dy_ld * 2);
   int bn, splits;
   plan(d, &bn, &splits, &p.steps_per_split, &p.steps);
   p.out = splits == 1 ? dw : (float*)workspace;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(ceil_div(p.K, 128), ceil_div(p.Cout, bn), splits);
+  constexpr int ST = 4;
   if (bn == 128)
-    hipLaunchKernelGGL(conv_wgrad_kernel<128>, grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<128, ST>), grid, dim3(256), ST * (8192 + 8192), s, p);
   else if (bn == 64)
-    hipLaunchKernelGGL(conv_wgrad_kernel<64>, grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<64, ST>), grid, dim3(256), ST * (8192 + 4096), s, p);
   else
-    hipLaunchKernelGGL(conv_wgrad_kernel<32>, grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<32, ST>), grid, dim3(256), ST * (8192 + 4096), s, p);
   DY_CHECK_LAUNCH();
   if (splits > 1) {
     const int64_t n = (int64_t)p.K * p.Cout;
-    int g = ceil_div(n, 256);
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(g), dim3(256), 0, s, (const float*)workspace, dw, n, splits);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(n, 64)), dim3(256), 0, s, (const float*)workspace, dw, n,
+                       splits);
     DY_CHECK_LAUNCH();
   }
   return DISYOLO_OK;
@@ -346,7 +399,7 @@ extern "C" int disyolo_conv_first_wgrad(const float* images, const void* dy, flo
                      (float*)workspace, B, H, W, Cout, 1024);
   DY_CHECK_LAUNCH();
   const int64_t n = 27 * Cout;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, (const float*)workspace, dw, n,
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(n, 64)), dim3(256), 0, s, (const float*)workspace, dw, n,
                      blocks);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;

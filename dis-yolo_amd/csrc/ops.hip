@@ -97,6 +97,57 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* w, bf16* o
   }
 }
 
+// ---- all layers in one launch: a device table of jobs, blocks find their job by prefix
+struct PackJob {
+  const float* w;   // f32 HWIO master
+  bf16* fwd;        // [Cout][K] or null
+  bf16* dgrad;      // [Cin][taps*cout_pad] or null
+  int K, Cout, Cin, taps, cout_pad;
+  int blk0;         // first block of this job's forward part
+  int blk1;         // first block of its dgrad part (== next job's blk0 when none)
+  int tiles_k;      // forward tiles along K
+};
+__global__ __launch_bounds__(256) void pack_all_kernel(const PackJob* jobs, int njobs) {
+  __shared__ float t[64][65];
+  int lo = 0, hi = njobs - 1;
+  const int bid = blockIdx.x;
+  while (lo < hi) {  // last job whose blk0 <= bid
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].blk0 <= bid) lo = mid; else hi = mid - 1;
+  }
+  const PackJob j = jobs[lo];
+  if (bid < j.blk1) {
+    const int tb = bid - j.blk0;
+    const int k0 = (tb % j.tiles_k) * 64, n0 = (tb / j.tiles_k) * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+      const int kk = i / 64, nn = i % 64;
+      float v = 0.f;
+      if (k0 + kk < j.K && n0 + nn < j.Cout) v = j.w[(size_t)(k0 + kk) * j.Cout + n0 + nn];
+      t[kk][nn] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+      const int nn = i / 64, kk = i % 64;
+      if (k0 + kk < j.K && n0 + nn < j.Cout) j.fwd[(size_t)(n0 + nn) * j.K + k0 + kk] = (bf16)t[kk][nn];
+    }
+  } else {
+    // dgrad part: 4096 output elements per block
+    const int64_t total = (int64_t)j.Cin * j.taps * j.cout_pad;
+    const int64_t base = (int64_t)(bid - j.blk1) * 4096;
+    for (int e = threadIdx.x; e < 4096; e += 256) {
+      const int64_t i = base + e;
+      if (i >= total) break;
+      const int co = (int)(i % j.cout_pad);
+      const int64_t r = i / j.cout_pad;
+      const int tp = (int)(r % j.taps);
+      const int ci = (int)(r / j.taps);
+      float v = 0.f;
+      if (co < j.Cout) v = j.w[((size_t)(j.taps - 1 - tp) * j.Cin + ci) * j.Cout + co];
+      j.dgrad[i] = (bf16)v;
+    }
+  }
+}
+
 // ---- TF-form Adam (train_yolo3_mask.py:55) ------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, float* m, float* v, int64_t n,
                                                    int64_t n_decay, float lr_t, float b1, float b2, float eps,
@@ -148,11 +199,11 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* w, int64_t n, f
   if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 __global__ void sumsq_final_kernel(const float* part, int nb, float coef, float* out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < nb; ++i) s += (double)part[i];
-    out[0] = (float)(s * coef);
-  }
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 64) s += (double)part[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) out[0] = (float)(s * coef);
 }
 
 }  // namespace
@@ -192,6 +243,40 @@ extern "C" int disyolo_pack_weights(const float* w_hwio, void* w_fwd, void* w_dg
                        cout_pad);
     DY_CHECK_LAUNCH();
   }
+  return DISYOLO_OK;
+}
+
+// host-side job description (include/disyolo.h: disyolo_pack_job); the device table is built
+// by the caller with disyolo_pack_table_build and lives in caller memory
+extern "C" size_t disyolo_pack_table_bytes(int njobs) { return (size_t)njobs * sizeof(PackJob); }
+
+extern "C" int disyolo_pack_table_build(const disyolo_pack_job* jobs, int njobs, void* host_table, int* total_blocks) {
+  DY_REQUIRE(jobs && njobs > 0 && host_table && total_blocks, "pack_table_build: bad args");
+  PackJob* t = (PackJob*)host_table;
+  int blk = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const disyolo_pack_job& s = jobs[i];
+    DY_REQUIRE(s.w_hwio && s.w_fwd && s.ksize > 0 && s.Cin > 0 && s.Cout > 0, "pack_table_build: job %d incomplete", i);
+    PackJob& d = t[i];
+    d.w = s.w_hwio; d.fwd = (bf16*)s.w_fwd; d.dgrad = (bf16*)s.w_dgrad;
+    d.taps = s.ksize * s.ksize; d.K = d.taps * s.Cin; d.Cout = s.Cout; d.Cin = s.Cin;
+    d.cout_pad = s.cout_pad > s.Cout ? s.cout_pad : s.Cout;
+    d.tiles_k = ceil_div(d.K, 64);
+    d.blk0 = blk;
+    blk += d.tiles_k * ceil_div(d.Cout, 64);
+    d.blk1 = blk;
+    if (d.dgrad) blk += ceil_div((int64_t)d.Cin * d.taps * d.cout_pad, 4096);
+  }
+  *total_blocks = blk;
+  return DISYOLO_OK;
+}
+
+extern "C" int disyolo_pack_all(const void* device_table, int njobs, int total_blocks, void* stream) {
+  DY_REQUIRE(device_table && njobs > 0 && total_blocks > 0, "pack_all: bad args");
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_pack_all(device_table, njobs, total_blocks, s); });
+  hipLaunchKernelGGL(pack_all_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackJob*)device_table,
+                     njobs);
+  DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }
 

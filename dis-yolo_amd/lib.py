@@ -54,6 +54,9 @@ _SIGS = {
     "disyolo_conv_first_wgrad_workspace": (C.c_size_t, [C.c_int] * 4),
     "disyolo_conv_first_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "disyolo_pack_weights": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
+    "disyolo_pack_table_bytes": (C.c_size_t, [C.c_int]),
+    "disyolo_pack_table_build": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
+    "disyolo_pack_all": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "disyolo_bn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64] + [C.c_void_p] * 4 +
                             [C.c_float, C.c_float] + [C.c_void_p] * 5),
     "disyolo_colstats_rows": (C.c_int, [C.c_int64, C.c_int]),
@@ -311,6 +314,32 @@ def conv_first_wgrad(images, dy, dw, ws: Workspace) -> None:
 def pack_weights(w_hwio, w_fwd, w_dgrad, ksize, cin, cout, cout_pad=0) -> None:
     _check(load().disyolo_pack_weights(_p(w_hwio), _p(w_fwd), _p(w_dgrad), ksize, cin, cout, max(cout_pad, cout),
                                        _stream()), "pack_weights")
+
+
+class PackJob(C.Structure):
+    """mirror of ``disyolo_pack_job``"""
+    _fields_ = [("w_hwio", C.c_void_p), ("w_fwd", C.c_void_p), ("w_dgrad", C.c_void_p),
+                ("ksize", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("cout_pad", C.c_int32)]
+
+
+class PackTable:
+    """Device-resident job table for pack_all: every trainable layer re-packed by one launch."""
+
+    def __init__(self, jobs, device):
+        n = len(jobs)
+        arr = (PackJob * n)()
+        for i, (w, wf, wd, k, cin, cout, pad) in enumerate(jobs):
+            arr[i] = PackJob(_p(w), _p(wf), _p(wd), k, cin, cout, pad)
+        nbytes = load().disyolo_pack_table_bytes(n)
+        host = (C.c_char * nbytes)()
+        blocks = C.c_int(0)
+        _check(load().disyolo_pack_table_build(arr, n, host, C.byref(blocks)), "pack_table_build")
+        self.n, self.blocks = n, blocks.value
+        self.dev = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(device)
+        self.keep = jobs
+
+    def run(self) -> None:
+        _check(load().disyolo_pack_all(_p(self.dev), self.n, self.blocks, _stream()), "pack_all")
 
 
 def bn_finalize(stats, rows, C_, count, gamma, beta, mm, mv, decay, eps, scale, shift, mean, rstd) -> None:

@@ -150,6 +150,7 @@ class YOLONet(object):
         self._prog = None       # recorded command list of one training step
         self._prog_marks = []   # [(command index, layer)] all-reduce trigger points
         self._graph = None      # hipGraph of the recorded step (single GPU)
+        self._pack_table = None
         self._init_params(seed, xavier_locked)
         self._plan(self.batchsize, self.image_size)
 
@@ -587,9 +588,12 @@ class YOLONet(object):
             L.adam_step_dev(self.arena, self.grad_arena, self.adam_m, self.adam_v, self.n_params, self.n_decay,
                             self.learning_rate, cfg.ADAM_BETA1, cfg.ADAM_BETA2, cfg.ADAM_EPSILON, self.l2,
                             self.step_dev, grad_scale)
-        for l in self.layers:
-            if not l.lock and l.idx > 1:
-                L.pack_weights(l.w, l.wp, l.wdg, l.k, l.cin, l.cout, l.cout_pad)
+        if self._pack_table is None:
+            jobs = [(l.w, l.wp, l.wdg, l.k, l.cin, l.cout, l.cout_pad) for l in self.layers
+                    if not l.lock and l.idx > 1]
+            self._pack_table = L.PackTable(jobs, self.device) if jobs else False
+        if self._pack_table:
+            self._pack_table.run()
 
     def total_loss(self) -> torch.Tensor:
         """conf + class + coord + mask + l2 term as a device scalar (tf.losses.get_total_loss,

@@ -105,6 +105,19 @@ int disyolo_conv_first_wgrad(const float* images, const void* dy, float* dw, int
 int disyolo_pack_weights(const float* w_hwio, void* w_fwd, void* w_dgrad, int ksize, int Cin,
                          int Cout, int cout_pad, void* stream);
 
+/* the same for many layers in ONE launch (re-pack after every optimizer step): the caller
+ * builds a table with pack_table_build (host memory, pack_table_bytes(njobs) bytes), copies it
+ * to the device once, and calls pack_all each step */
+typedef struct disyolo_pack_job {
+  const float* w_hwio;
+  void* w_fwd;
+  void* w_dgrad;      /* or NULL */
+  int32_t ksize, Cin, Cout, cout_pad;
+} disyolo_pack_job;
+size_t disyolo_pack_table_bytes(int njobs);
+int disyolo_pack_table_build(const disyolo_pack_job* jobs, int njobs, void* host_table, int* total_blocks);
+int disyolo_pack_all(const void* device_table, int njobs, int total_blocks, void* stream);
+
 /* ---- batch normalisation (yolo/yolo3_net_pos.py:71-107) ---- */
 /* stats partials -> batch mean / population variance; scale = gamma*rsqrt(var+eps),
  * shift = beta - mean*scale; moving <- decay*moving + (1-decay)*batch (:93-96). */
