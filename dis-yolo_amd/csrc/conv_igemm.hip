@@ -13,6 +13,7 @@
 // register-staged global->LDS copies issued one K-step ahead.  LDS rows are 64 B (32
 // bf16); the 16-byte chunk index is XOR-swizzled so ds_read_b128 fragment reads are
 // bank-conflict free (see DESIGN.md "LDS layout").
+#include <utility>
 #include "common.h"
 #include "runtime.h"
 
@@ -56,11 +57,26 @@ __device__ __forceinline__ int swz(int row, int chunk) {
 // destination, so it is register-safe).  Nothing else in this kernel uses M0.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned OOB = 0x80000000u;
-__device__ __forceinline__ void dma16(unsigned voff, i32x4 srd, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+// address = descriptor base + voff (per lane) + soff (wave-uniform SGPR); the range check
+// covers voff + soff (probed: tools/probe_lds_dma2.hip), so OOB lanes stay out of range.
+template <int LDS_IMM>
+__device__ __forceinline__ void dma16(unsigned voff, i32x4 srd, unsigned soff, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                :
-               : "v"(voff), "s"(srd), "s"(lds_dst)
+               : "v"(voff), "s"(srd), "s"(soff), "s"(lds_base + LDS_IMM)
                : "memory");
+}
+// m / d and m % d for 0 <= m < 2^24 via one float division and a +-1 fix-up
+__device__ __forceinline__ void divmod_small(int m, int d, int& q, int& r) {
+  q = (int)(__fdividef((float)m, (float)d));
+  r = m - q * d;
+  if (r < 0) {
+    --q;
+    r += d;
+  } else if (r >= d) {
+    ++q;
+    r -= d;
+  }
 }
 __device__ __forceinline__ i32x4 make_srd(const void* base, unsigned bytes) {
   i32x4 r;
@@ -76,7 +92,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int BM, int BN, int WM, int WN, int BK, int ST>
-__global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
+__global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void conv_igemm_kernel(ConvParams p) {
   constexpr int NW = WM * WN;
   constexpr int T = NW * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -122,7 +138,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
   const i32x4 srd1 = make_srd(p.x1 ? (const void*)p.x1 : (const void*)p.x0, p.x1 ? p.bytes1 : 0u);
   const i32x4 srdw = make_srd(p.w, p.bytesw);
   int a_iy0[AI], a_ix0[AI], a_b[AI];
-  unsigned a_kb[AI], a_base[AI], a_base1[AI];
+  unsigned a_kb[AI], a_base[AI], a_base1[AI], a_org[AI];
   bool a_ok[AI];
 #pragma unroll
   for (int j = 0; j < AI; ++j) {
@@ -131,11 +147,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
     const int m = m0 + row;
     a_ok[j] = (row < BM) && (m < p.M);
     const int mm = a_ok[j] ? m : 0;
-    const int hw = p.Ho * p.Wo;
-    const int b = mm / hw;
-    const int rem = mm - b * hw;
-    const int yo = rem / p.Wo;
-    const int xo = rem - yo * p.Wo;
+    int b, rem, yo, xo;
+    if (p.M < (1 << 24)) {
+      divmod_small(mm, p.Ho * p.Wo, b, rem);
+      divmod_small(rem, p.Wo, yo, xo);
+    } else {
+      const int hw = p.Ho * p.Wo;
+      b = mm / hw;
+      rem = mm - b * hw;
+      yo = rem / p.Wo;
+      xo = rem - yo * p.Wo;
+    }
     a_b[j] = b;
     a_iy0[j] = yo * p.stride - p.pad_t;
     a_ix0[j] = xo * p.stride - p.pad_l;
@@ -145,6 +167,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
       const int H1 = p.H >> 1, W1 = p.W >> 1;
       a_base1[j] = a_ok[j] ? (unsigned)(((a_b[j] * H1 + (a_iy0[j] >> 1)) * W1 + (a_ix0[j] >> 1)) * p.C1) * 2u + a_kb[j] : OOB;
     }
+    // forward gather: tap (kh,kw) sits at a fixed byte distance from tap (0,0); keep that
+    // origin (it may lie outside the image: modular arithmetic) and a validity bit per tap
+    a_org[j] = (unsigned)(((a_b[j] * p.H + a_iy0[j]) * p.W + a_ix0[j]) * p.C0) * 2u + a_kb[j];
   }
   unsigned b_base[BI];
 #pragma unroll
@@ -160,29 +185,41 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
   auto issue_tile = [&](int stage) {
     const unsigned sbase = lds0 + stage * STB + wave * 1024;
     if (ci0 == 0) {  // new filter tap (wave-uniform): refresh the per-lane pixel offsets
+      if (p.dshift == 0) {
+        const unsigned tapoff = (unsigned)((kh * p.W + kw) * p.C0) * 2u;
 #pragma unroll
-      for (int j = 0; j < AI; ++j) {
-        int iy = a_iy0[j] + kh, ix = a_ix0[j] + kw;
-        // transposed gather of a stride-2 data gradient: only even taps are real
-        bool ok = a_ok[j] && (((iy | ix) & p.dmask) == 0);
-        iy >>= p.dshift;
-        ix >>= p.dshift;
-        ok = ok && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
-        a_base[j] = ok ? (unsigned)(((a_b[j] * p.H + iy) * p.W + ix) * p.C0) * 2u + a_kb[j] : OOB;
+        for (int j = 0; j < AI; ++j) {
+          const bool ok = a_ok[j] && ((unsigned)(a_iy0[j] + kh) < (unsigned)p.H) && ((unsigned)(a_ix0[j] + kw) < (unsigned)p.W);
+          a_base[j] = ok ? a_org[j] + tapoff : OOB;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < AI; ++j) {
+          int iy = a_iy0[j] + kh, ix = a_ix0[j] + kw;
+          // transposed gather of a stride-2 data gradient: only even taps are real
+          bool ok = a_ok[j] && (((iy | ix) & p.dmask) == 0);
+          iy >>= p.dshift;
+          ix >>= p.dshift;
+          ok = ok && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
+          a_base[j] = ok ? (unsigned)(((a_b[j] * p.H + iy) * p.W + ix) * p.C0) * 2u + a_kb[j] : OOB;
+        }
       }
     }
     if (ci0 < p.C0) {
       const unsigned cs2 = ci0 * 2;
-#pragma unroll
-      for (int j = 0; j < AI; ++j) dma16(a_base[j] + cs2, srd0, sbase + j * SLAB);
+      [&]<int... J>(std::integer_sequence<int, J...>) {
+        (dma16<J * SLAB>(a_base[J], srd0, cs2, sbase), ...);
+      }(std::make_integer_sequence<int, AI>{});
     } else {
       const unsigned cs2 = (ci0 - p.C0) * 2;
-#pragma unroll
-      for (int j = 0; j < AI; ++j) dma16(a_base1[j] + cs2, srd1, sbase + j * SLAB);
+      [&]<int... J>(std::integer_sequence<int, J...>) {
+        (dma16<J * SLAB>(a_base1[J], srd1, cs2, sbase), ...);
+      }(std::make_integer_sequence<int, AI>{});
     }
     const unsigned k2 = k0 * 2;
-#pragma unroll
-    for (int j = 0; j < BI; ++j) dma16(b_base[j] + k2, srdw, sbase + A_BYTES + j * SLAB);
+    [&]<int... J>(std::integer_sequence<int, J...>) {
+      (dma16<A_BYTES + J * SLAB>(b_base[J], srdw, k2, sbase), ...);
+    }(std::make_integer_sequence<int, BI>{});
     // advance the K cursor by one BK-wide slice
     k0 += BK;
     ci0 += BK;

@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdisyolo_hip.so")
+LIB_PATH = os.environ.get("DISYOLO_LIB", os.path.join(_HERE, "libdisyolo_hip.so"))
 
 GRAD_LD = 32
 ROI_MAX = 16
