@@ -12,7 +12,7 @@ namespace {
 // ---- stage 2 of every column reduction: partial[rows][C][Q] -> f64 sums ------------
 // 256 threads = 8 channels x 32 row lanes; each lane strides over the partial rows, the
 // 32 lane sums are combined through LDS in a fixed order (deterministic).
-constexpr int FIN_CPB = 8;
+constexpr int FIN_CPB = 2;
 template <int Q>
 __device__ __forceinline__ bool block_sum_partials(const float* part, int rows, int C, double* res /*[Q]*/, int* c_out) {
   constexpr int LANES = 256 / FIN_CPB;
@@ -23,7 +23,19 @@ __device__ __forceinline__ bool block_sum_partials(const float* part, int rows, 
 #pragma unroll
   for (int q = 0; q < Q; ++q) acc[q] = 0.0;
   if (c < C) {
-    for (int r = g; r < rows; r += LANES) {
+    int r = g;
+    for (; r + 3 * LANES < rows; r += 4 * LANES) {   // four independent loads in flight
+      float v[4][Q];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) v[u][q] = part[((size_t)(r + u * LANES) * C + c) * Q + q];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[q] += (double)v[u][q];
+    }
+    for (; r < rows; r += LANES) {
 #pragma unroll
       for (int q = 0; q < Q; ++q) acc[q] += (double)part[((size_t)r * C + c) * Q + q];
     }

@@ -3,10 +3,21 @@
 #include "runtime.h"
 
 namespace {
+// A command runs on lane 0 (the caller's stream) or lane 1 (a side stream owned by the
+// list).  kind 0 = launch, 1 = "lane `to` waits for everything lane `from` has enqueued".
+struct Cmd {
+  std::function<int(void*)> fn;
+  int kind, lane, from, to;
+  hipEvent_t ev;
+};
 struct CmdList {
-  std::vector<std::function<int(void*)>> cmds;
+  std::vector<Cmd> cmds;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool uses_side = false;
 };
 thread_local CmdList* g_rec = nullptr;
+thread_local int g_lane = 0;
 
 __global__ __launch_bounds__(256) void add_bf16_kernel(const uint4* src, uint4* dst, int64_t nvec, int accumulate) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -27,15 +38,54 @@ __global__ __launch_bounds__(256) void add_bf16_kernel(const uint4* src, uint4* 
 
 bool dy_recording() { return g_rec != nullptr; }
 int dy_record(std::function<int(void*)> fn) {
-  g_rec->cmds.push_back(std::move(fn));
+  g_rec->cmds.push_back(Cmd{std::move(fn), 0, g_lane, 0, 0, nullptr});
+  if (g_lane) g_rec->uses_side = true;
   return DISYOLO_OK;
 }
 
-extern "C" void* disyolo_cmdlist_create(void) { return new CmdList(); }
-extern "C" void disyolo_cmdlist_destroy(void* l) { delete (CmdList*)l; }
+extern "C" void* disyolo_cmdlist_create(void) {
+  CmdList* c = new CmdList();
+  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+    c->side = nullptr;  // no device (CPU-only build check): lists can still be recorded, not run
+  }
+  return c;
+}
+extern "C" void disyolo_cmdlist_destroy(void* l) {
+  CmdList* c = (CmdList*)l;
+  if (!c) return;
+  for (Cmd& k : c->cmds)
+    if (k.ev) (void)hipEventDestroy(k.ev);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->side) (void)hipStreamDestroy(c->side);
+  delete c;
+}
 extern "C" int disyolo_cmdlist_begin(void* l) {
   DY_REQUIRE(l && !g_rec, "cmdlist_begin: null list or already recording");
   g_rec = (CmdList*)l;
+  g_lane = 0;
+  return DISYOLO_OK;
+}
+// lane for the following launches of the recording thread (no-op when not recording: the
+// per-call path runs everything on the caller's stream, which is trivially ordered)
+extern "C" int disyolo_cmdlist_set_lane(int lane) {
+  DY_REQUIRE(lane == 0 || lane == 1, "cmdlist_set_lane: lane must be 0 or 1");
+  if (g_rec) g_lane = lane;
+  return DISYOLO_OK;
+}
+// lane `to` waits for everything recorded so far on lane `from` (no-op when not recording)
+extern "C" int disyolo_cmdlist_sync(int from, int to) {
+  DY_REQUIRE((from == 0 || from == 1) && (to == 0 || to == 1) && from != to, "cmdlist_sync: bad lanes");
+  if (!g_rec) return DISYOLO_OK;
+  hipEvent_t ev;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+    disyolo_set_error("cmdlist_sync: hipEventCreate failed");
+    return DISYOLO_E_HIP;
+  }
+  g_rec->cmds.push_back(Cmd{nullptr, 1, 0, from, to, ev});
+  g_rec->uses_side = true;
   return DISYOLO_OK;
 }
 extern "C" int disyolo_cmdlist_end(void) {
@@ -48,9 +98,34 @@ extern "C" int disyolo_cmdlist_run(void* l, int first, int last, void* stream) {
   DY_REQUIRE(l && !g_rec, "cmdlist_run: null list or called while recording");
   CmdList* c = (CmdList*)l;
   DY_REQUIRE(first >= 0 && last <= (int)c->cmds.size() && first <= last, "cmdlist_run: bad range [%d,%d)", first, last);
+  hipStream_t lanes[2] = {(hipStream_t)stream, c->side};
+  const bool side = c->uses_side;
+  if (side) {
+    DY_REQUIRE(c->side, "cmdlist_run: side stream unavailable");
+    // every replayed range is self-contained: the side lane starts after the caller's prior
+    // work and is joined back before returning
+    if (hipEventRecord(c->ev_fork, lanes[0]) != hipSuccess || hipStreamWaitEvent(lanes[1], c->ev_fork, 0) != hipSuccess) {
+      disyolo_set_error("cmdlist_run: fork failed");
+      return DISYOLO_E_HIP;
+    }
+  }
   for (int i = first; i < last; ++i) {
-    const int rc = c->cmds[i](stream);
-    if (rc) return rc;
+    Cmd& k = c->cmds[i];
+    if (k.kind == 0) {
+      const int rc = k.fn(lanes[k.lane]);
+      if (rc) return rc;
+    } else {
+      if (hipEventRecord(k.ev, lanes[k.from]) != hipSuccess || hipStreamWaitEvent(lanes[k.to], k.ev, 0) != hipSuccess) {
+        disyolo_set_error("cmdlist_run: lane sync failed");
+        return DISYOLO_E_HIP;
+      }
+    }
+  }
+  if (side) {
+    if (hipEventRecord(c->ev_join, lanes[1]) != hipSuccess || hipStreamWaitEvent(lanes[0], c->ev_join, 0) != hipSuccess) {
+      disyolo_set_error("cmdlist_run: join failed");
+      return DISYOLO_E_HIP;
+    }
   }
   return DISYOLO_OK;
 }

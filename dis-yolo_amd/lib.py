@@ -92,6 +92,8 @@ _SIGS = {
     "disyolo_cmdlist_begin": (C.c_int, [C.c_void_p]),
     "disyolo_cmdlist_end": (C.c_int, []),
     "disyolo_cmdlist_size": (C.c_int, [C.c_void_p]),
+    "disyolo_cmdlist_set_lane": (C.c_int, [C.c_int]),
+    "disyolo_cmdlist_sync": (C.c_int, [C.c_int, C.c_int]),
     "disyolo_cmdlist_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "disyolo_l2_workspace": (C.c_size_t, [C.c_int64]),
     "disyolo_l2_loss": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -430,6 +432,14 @@ def psroi_assemble(score, detections, B, max_det, map_size, k, masks, keep) -> N
 def adam_step(w, grad, m, v, n, n_decay, lr, b1, b2, eps, l2, t, grad_scale=1.0) -> None:
     _check(load().disyolo_adam_step(_p(w), _p(grad), _p(m), _p(v), n, n_decay, lr, b1, b2, eps, l2, t, grad_scale,
                                     _stream()), "adam_step")
+
+
+def set_lane(lane: int) -> None:
+    _check(load().disyolo_cmdlist_set_lane(lane), "cmdlist_set_lane")
+
+
+def lane_sync(src: int, dst: int) -> None:
+    _check(load().disyolo_cmdlist_sync(src, dst), "cmdlist_sync")
 
 
 def adam_step_dev(w, grad, m, v, n, n_decay, lr, b1, b2, eps, l2, step_counter, grad_scale=1.0) -> None:

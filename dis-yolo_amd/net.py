@@ -16,6 +16,7 @@ from __future__ import annotations
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import math
+import os
 import numpy as np
 import torch
 
@@ -141,6 +142,7 @@ class YOLONet(object):
         self.device = torch.device(device)
         L.load()
         self.ws = L.Workspace(self.device)
+        self.ws_aux = L.Workspace(self.device)      # scratch of the side lane (weight gradients)
         # lock map: stage 1 = conv1-52 locked (shipped source), stage 2 = all trainable
         self.lock = dict(lock) if lock is not None else {i: (stage == 1 and i <= 52) for i in range(1, 83)}
         self.layers = build_topology(self.num_class, self.k)
@@ -151,6 +153,7 @@ class YOLONet(object):
         self._prog_marks = []   # [(command index, layer)] all-reduce trigger points
         self._graph = None      # hipGraph of the recorded step (single GPU)
         self._pack_table = None
+        self.use_side_lane = os.environ.get("DISYOLO_SIDE_LANE", "1") != "0"
         self._init_params(seed, xavier_locked)
         self._plan(self.batchsize, self.image_size)
 
@@ -370,6 +373,7 @@ class YOLONet(object):
                     need = max(need, L.load().disyolo_bn_act_bwd_workspace(B * l.Ho * l.Wo, l.cout))
             need = max(need, L.load().disyolo_conv_first_wgrad_workspace(B, S, S, 32))
             self.ws.get(int(need))
+            self.ws_aux.get(int(need))
         self.ws.get(int(max(L.load().disyolo_detect_workspace(B, S, self.num_class), 1 << 20)))
         self._build_dgrad_descs()
         self.refresh_weights()
@@ -560,10 +564,19 @@ class YOLONet(object):
                     if sc.grad is not None:
                         L.add_bf16(l.grad, sc.grad, accumulate=sc.grad_set)
                         sc.grad_set = True
+            # the weight gradient is off the critical chain (dx -> dgrad -> next layer's BN
+            # backward): in a recorded step it runs on the side lane, overlapping the small
+            # latency-bound BN kernels of the following layers
+            side = self.use_side_lane
+            if side:
+                L.lane_sync(0, 1)
+                L.set_lane(1)
             if l.idx == 1:
-                L.conv_first_wgrad(self.images, l.dx, l.dw, self.ws)
+                L.conv_first_wgrad(self.images, l.dx, l.dw, self.ws_aux)
             else:
-                L.conv2d_wgrad(l.wgrad_desc, dx, ld, l.dw, self.ws)
+                L.conv2d_wgrad(l.wgrad_desc, dx, ld, l.dw, self.ws_aux)
+            if side:
+                L.set_lane(0)
             for mode, tgt, kw in l.dgrad_descs:
                 if mode == "direct":
                     self._accumulate_into(tgt, kw, dx, l.cin, l.k, l.stride)
@@ -575,6 +588,7 @@ class YOLONet(object):
                     up.grad_set = True
             if on_layer_done is not None:
                 on_layer_done(l)
+        L.lane_sync(1, 0)
 
     @property
     def step_count(self) -> int:
@@ -618,12 +632,17 @@ class YOLONet(object):
                 L.l2_loss(self.arena, self.n_decay, self.l2, self.reg_loss, self.ws)
             if self.dp is not None:
                 triggers = self.dp.by_trigger
-                self.backward(lambda l: marks.append((prog.size(), l)) if l.idx in triggers else None)
+                def mark(l):
+                    if l.idx in triggers:
+                        L.lane_sync(1, 0)          # the bucket's weight gradients are on the side lane
+                        marks.append((prog.size(), l))
+                self.backward(mark)
             else:
                 self.backward()
             self._bwd_end = prog.size()
             self.optimizer_step(1.0 / self.dp.world_size if self.dp is not None else 1.0)
         self.ws.frozen = True
+        self.ws_aux.frozen = True
         self._prog, self._prog_marks = prog, marks
         if graph:
             if self.dp is not None:
