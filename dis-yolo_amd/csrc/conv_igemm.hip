@@ -144,7 +144,7 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void
   for (int j = 0; j < AI; ++j) {
     const int chunk = (j * NW + wave) * 64 + lane;
     const int row = chunk / CPR, pc = chunk % CPR;
-    const int m = m0 + row;
+    const int m = ((p.flags & 0x1000) ? 0 : m0) + row;   // 0x1000: timing probe, every block gathers tile 0
     a_ok[j] = (row < BM) && (m < p.M);
     const int mm = a_ok[j] ? m : 0;
     int b, rem, yo, xo;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void
   for (int j = 0; j < BI; ++j) {
     const int chunk = (j * NW + wave) * 64 + lane;
     const int row = chunk / CPR, pc = chunk % CPR;
-    const int n = n0 + row;
+    const int n = ((p.flags & 0x2000) ? 0 : n0) + row;   // 0x2000: timing probe, every block reads weight tile 0
     b_base[j] = ((row < BN) && (n < p.Cout)) ? (unsigned)n * (unsigned)p.K * 2u + swz<BK>(row, pc) * 16 : OOB;
   }
 
@@ -247,6 +247,9 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void
     if (s < p.nk) issue_tile(s);
 
   const int frow = lane & 15, fchunk = lane >> 4;
+#ifdef DY_PROBE
+  bf16x8 pxf[2][MI], pwf[2][NI];
+#endif
   for (int kt = 0; kt < p.nk; ++kt) {
     if (PRE >= 1 && kt + PRE - 1 < p.nk)
       wait_vmcnt<LPT*(PRE >= 1 ? PRE - 1 : 0)>();
@@ -254,6 +257,56 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void
       wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifdef DY_PROBE
+    // ablation build (tools/bin/libdisyolo_probe.so): 0x4000 = no DMA in the loop,
+    // 0x8000 = fragments read once, 0x10000 = no MFMA
+    if (PRE >= 1) {
+      if (kt + PRE < p.nk && !(p.flags & 0x4000)) issue_tile((kt + PRE) % ST);
+    }
+    const char* sA = smem + (kt % ST) * STB;
+    const char* sB = sA + A_BYTES;
+    static_assert(BK / 32 <= 2, "");
+    bf16x8 xf[2][MI], wf[2][NI];
+    if (!(p.flags & 0x8000) || kt == 0) {
+#pragma unroll
+      for (int kk = 0; kk < BK / 32; ++kk) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int row = wm * WTM + i * 16 + frow;
+          pxf[kk][i] = *reinterpret_cast<const bf16x8*>(sA + row * ROWB + swz<BK>(row, kk * 4 + fchunk) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int row = wn * WTN + j * 16 + frow;
+          pwf[kk][j] = *reinterpret_cast<const bf16x8*>(sB + row * ROWB + swz<BK>(row, kk * 4 + fchunk) * 16);
+        }
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) xf[kk][i] = pxf[kk][i];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) wf[kk][j] = pwf[kk][j];
+    }
+    if (!(p.flags & 0x10000)) {
+#pragma unroll
+      for (int kk = 0; kk < BK / 32; ++kk)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][j], xf[kk][i], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < BK / 32; ++kk) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(xf[kk][i]));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(wf[kk][j]));
+      }
+    }
+#else
     if (PRE >= 1) {
       if (kt + PRE < p.nk) issue_tile((kt + PRE) % ST);
     }
@@ -278,6 +331,7 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
     }
+#endif
     if (PRE == 0) {  // single stage: refill only after everyone has consumed the tile
       __builtin_amdgcn_s_barrier();
       if (kt + 1 < p.nk) issue_tile(0);
