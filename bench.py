@@ -76,6 +76,50 @@ def cpu_baseline(stage: int, size: int, budget_s: float = 25.0):
                       % (n, B, size, size, stage, dt)}
 
 
+def bench_infer(args, dev, world, rank):
+    """Secondary measurement (BASELINE.json config 4): inference-only, batch 32 by default,
+    network + decode/NMS + position-sensitive mask assembly, hipGraph-captured."""
+    B = args.batch if args.batch != 8 else 32
+    S = args.size
+    net = YOLONet(training=False, device=dev, image_size=S, batch_size=B, stage=1, seed=0)
+    batch = synthetic_batch(B, S, seed=1234 + rank)
+    net._set_inputs(batch["images"], batch["clip_window"])
+    net.build_infer_program(graph=(args.mode in ("auto", "graph")))
+    for _ in range(args.warmup):
+        net.infer()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        net.infer()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        value = world * B * args.steps / dt
+        gf = FWD_GFLOP_PER_IMG_576 * (S / 576.0) ** 2
+        print(json.dumps({
+            "metric": "inference images/sec @%dx%d bf16 (network + NMS + PS-RoI mask assembly)" % (S, S),
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "infer_B%d_%dx%d_3class" % (B, S, S), "images_per_gpu": B,
+                       "step_driver": "graph" if net._infer_graph is not None else "program",
+                       "detections_in_batch": int(net.det_count.sum().item())},
+            "model_flops": {"fwd_gflop_per_image": round(gf, 2),
+                            "achieved_tflops_per_gpu": round(gf * value / world / 1e3, 1),
+                            "frac_of_mfma_peak": round(gf * value / world / 1e3 / MFMA_PEAK_TFLOPS, 4)},
+            "reference_published": "README.md:23: ~0.1 s/image (10 img/s) on i7-7700 + GTX 1060, incl. host mask crop"}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,6 +129,9 @@ def main():
     ap.add_argument("--size", type=int, default=576)
     ap.add_argument("--stage", type=int, default=1, choices=(1, 2),
                     help="1 = conv1-52 locked (the reference's shipped source), 2 = all layers trainable")
+    ap.add_argument("--task", default="train", choices=("train", "infer"),
+                    help="train = the headline metric; infer = BASELINE.json config 4 (forward + detection filter + "
+                         "PS-RoI mask assembly, hipGraph replay), reported as a secondary line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--mode", default="auto", choices=("auto", "graph", "program", "eager"),
@@ -107,6 +154,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     B, S = args.batch, args.size
+    if args.task == "infer":
+        return bench_infer(args, dev, world, rank)
     net = YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=args.stage, seed=0)
     if world > 1:
         from disyolo_amd.dp import enable_data_parallel

@@ -490,6 +490,44 @@ class YOLONet(object):
                 det_mask.append(np.float32(0.0))
         return [det_box, det_mask]
 
+    def build_infer_program(self, det_thresh: float = cfg.OBJ_THRESHOLD, graph: bool = True) -> None:
+        """Record inference (network + detection filter + mask assembly) into a command list
+        and optionally a hipGraph; afterwards ``infer()`` is one replay.  Outputs stay on the
+        device, fixed-shape: detections [B,30,6], det_count [B], masks [B,30,S/2,S/2],
+        keep [B,30] (BASELINE.json config 4)."""
+        Sm = self.S // 2
+        if self.masks is None:
+            self.masks = torch.zeros(self.B, cfg.MAX_DETECTION, Sm, Sm, dtype=F32, device=self.device)
+        prog = L.CmdList()
+        with prog:
+            self._forward_layers(False)
+            self._detect(det_thresh)
+            L.psroi_assemble(self.by_idx[82].act, self.detections, self.B, cfg.MAX_DETECTION, Sm, self.k, self.masks,
+                             self.keep)
+        self.ws.frozen = True
+        self._infer_prog = prog
+        self._infer_graph = None
+        if graph:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                prog.run()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                prog.run()
+            self._infer_graph = g
+
+    def infer(self, images=None, clip_window=None):
+        """replay the recorded inference; returns (detections, det_count, masks, keep) on device"""
+        if images is not None:
+            self._set_inputs(images, clip_window)
+        if self._infer_graph is not None:
+            self._infer_graph.replay()
+        else:
+            self._infer_prog.run()
+        return self.detections, self.det_count, self.masks, self.keep
+
     # ------------------------------------------------------------------ training
     def set_batch(self, batch: Dict) -> None:
         """feed_dict of Solver.train (train_yolo3_mask.py:146-149)."""
