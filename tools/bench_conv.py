@@ -57,7 +57,7 @@ for key, idxs in sorted(shapes.items(), key=lambda kv: -kv[0][0]):
     row = []
     best = 1e9
     for t in tiles:
-        if (cout <= 32 and (t & 0xff) in (1, 2, 3, 6, 7, 8)) or (cout <= 64 and (t & 0xff) in (1, 3, 8)):
+        if (cout <= 32 and (t & 0xff) in (1, 3, 8)) or (cout <= 64 and (t & 0xff) in (1, 3, 8)) or (cout > 64 and (t & 0xff) in (4, 5)):
             row.append("        -"); continue
         d = L.make_conv_desc(x0, w, y, k, s, x1=x1, scale=sc, shift=sh, leaky=True, tile=t)
         dt = timeit(d)
