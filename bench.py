@@ -104,7 +104,7 @@ def bench_infer(args, dev, world, rank):
     if rank == 0:
         value = world * B * args.steps / dt
         gf = FWD_GFLOP_PER_IMG_576 * (S / 576.0) ** 2
-        print(json.dumps({
+        emit(({
             "metric": "inference images/sec @%dx%d bf16 (network + NMS + PS-RoI mask assembly)" % (S, S),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -120,7 +120,20 @@ def bench_infer(args, dev, world, rank):
         dist.destroy_process_group()
 
 
+def emit(obj) -> None:
+    """the ONE JSON line goes to the real stdout; everything else any library prints to fd 1
+    (RCCL's version banner, for one) has been re-routed to stderr by main()"""
+    os.write(_REAL_STDOUT, (json.dumps(obj) + "\n").encode())
+
+
+_REAL_STDOUT = 1
+
+
 def main():
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -134,6 +147,8 @@ def main():
                          "PS-RoI mask assembly, hipGraph replay), reported as a secondary line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="initialise RCCL and run the bucketed gradient all-reduce path even with one rank (self-test)")
     ap.add_argument("--mode", default="auto", choices=("auto", "graph", "program", "eager"),
                     help="how the step is driven: the recorded command list replayed by the native executor "
                          "(default; cut at the all-reduce points when N > 1), its hipGraph capture, or per-launch "
@@ -149,15 +164,17 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dp = world > 1 or args.force_dp
+    if use_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     B, S = args.batch, args.size
     if args.task == "infer":
         return bench_infer(args, dev, world, rank)
     net = YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=args.stage, seed=0)
-    if world > 1:
+    if use_dp:
         from disyolo_amd.dp import enable_data_parallel
         enable_data_parallel(net)
     batch = synthetic_batch(B, S, seed=1234 + rank)
@@ -224,7 +241,7 @@ def main():
                        "images_per_gpu": B, "global_batch": B * world, "image_size": S,
                        "stage": "1: conv1-52 locked (shipped reference source)" if args.stage == 1 else
                                 "2: all 82 layers trainable",
-                       "parallelism": "dp%d" % world, "optimizer": "adam(tf-form) lr=1e-4", "step_driver": mode,
+                       "parallelism": "dp%d" % world, "rccl_buckets": (len(net.dp.buckets) + 1) if net.dp else 0, "optimizer": "adam(tf-form) lr=1e-4", "step_driver": mode,
                        "final_total_loss": round(loss, 4)},
             "model_flops": {"train_gflop_per_image": round(train_gflop, 1),
                             "achieved_tflops_per_gpu": round(train_gflop * value / world / 1e3, 1),
@@ -251,8 +268,8 @@ def main():
             out["kernels"] = kernels
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.stage, S)
-        print(json.dumps(out))
-    if world > 1:
+        emit(out)
+    if use_dp:
         dist.destroy_process_group()
 
 
