@@ -65,6 +65,24 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* img, const
   }
 }
 
+// f32 [rows,3] image -> bf16 [rows,8] (channels 3..7 zero): the layout the MFMA weight-gradient
+// kernel needs to treat the first layer like every other one
+__global__ __launch_bounds__(256) void image_pad8_kernel(const float* img, uint4* out, int64_t rows) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += stride) {
+    const float v[8] = {img[i * 3], img[i * 3 + 1], img[i * 3 + 2], 0.f, 0.f, 0.f, 0.f, 0.f};
+    out[i] = pack8(v);
+  }
+}
+// dst[r][0:cols] = src[r][0:cols] with different row pitches (f32)
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* src, float* dst, int rows, int cols, int src_ld, int dst_ld) {
+  const int n = rows * cols;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int r = i / cols, c = i - r * cols;
+    dst[(size_t)r * dst_ld + c] = src[(size_t)r * src_ld + c];
+  }
+}
+
 // ---- weight packing: f32 HWIO -> bf16 [Cout][K] through a 64x64 LDS transpose ------
 __global__ __launch_bounds__(256) void pack_fwd_kernel(const float* w, bf16* out, int K, int Cout) {
   __shared__ float t[64][65];
@@ -219,6 +237,25 @@ extern "C" int disyolo_conv_first_fwd(const float* images, const float* w_hwio, 
   if (grid > 256 * 16) grid = 256 * 16;
   hipLaunchKernelGGL(conv_first_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, images, w_hwio, scale,
                      shift, (bf16*)y_bf16, B, H, W, alpha);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+extern "C" int disyolo_image_pad8(const float* images, void* out_bf16, int64_t pixels, void* stream) {
+  DY_REQUIRE(images && out_bf16 && pixels > 0, "image_pad8: bad args");
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_image_pad8(images, out_bf16, pixels, s); });
+  int64_t g = (pixels + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(image_pad8_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, images, (uint4*)out_bf16, pixels);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+extern "C" int disyolo_copy2d_f32(const float* src, float* dst, int rows, int cols, int src_ld, int dst_ld, void* stream) {
+  DY_REQUIRE(src && dst && rows > 0 && cols > 0 && src_ld >= cols && dst_ld >= cols, "copy2d: bad args");
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_copy2d_f32(src, dst, rows, cols, src_ld, dst_ld, s); });
+  hipLaunchKernelGGL(copy2d_kernel, dim3(ceil_div((int64_t)rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     rows, cols, src_ld, dst_ld);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }

@@ -53,6 +53,8 @@ _SIGS = {
                                        C.c_size_t, C.c_void_p]),
     "disyolo_conv_first_wgrad_workspace": (C.c_size_t, [C.c_int] * 4),
     "disyolo_conv_first_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "disyolo_image_pad8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "disyolo_copy2d_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "disyolo_pack_weights": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
     "disyolo_pack_table_bytes": (C.c_size_t, [C.c_int]),
     "disyolo_pack_table_build": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
@@ -311,6 +313,14 @@ def conv_first_wgrad(images, dy, dw, ws: Workspace) -> None:
     buf = ws.get(need)
     _check(load().disyolo_conv_first_wgrad(_p(images), _p(dy), _p(dw), B, H, W, cout, _p(buf), buf.numel(), _stream()),
            "conv_first_wgrad")
+
+
+def image_pad8(images, out) -> None:
+    _check(load().disyolo_image_pad8(_p(images), _p(out), images.numel() // 3, _stream()), "image_pad8")
+
+
+def copy2d_f32(src, dst, rows, cols, src_ld, dst_ld) -> None:
+    _check(load().disyolo_copy2d_f32(_p(src), _p(dst), rows, cols, src_ld, dst_ld, _stream()), "copy2d_f32")
 
 
 def pack_weights(w_hwio, w_fwd, w_dgrad, ksize, cin, cout, cout_pad=0) -> None:

@@ -333,6 +333,9 @@ class YOLONet(object):
                 l.wgrad_desc = L.make_conv_desc(x0, l.wp, l.act, l.k, l.stride, x1=x1)
         l1 = self.by_idx[1]
         if self.training and not l1.lock:
+            self._img8 = torch.zeros(B, S, S, 8, dtype=BF16, device=dev)
+            self._dw8 = torch.zeros(3, 3, 8, l1.cout, dtype=F32, device=dev)
+            self._wgrad1_desc = L.make_conv_desc(self._img8, l1.dx, l1.dx, 3, 1)
             l1.stats_rows = L.colstats_rows(B * S * S, l1.cout)
             l1.stats = torch.zeros(l1.stats_rows, l1.cout, 2, dtype=F32, device=dev)
             self._ones32 = torch.ones(l1.cout, dtype=F32, device=dev)
@@ -371,7 +374,9 @@ class YOLONet(object):
                     need = max(need, L.load().disyolo_conv2d_wgrad_workspace(ctypes.byref(l.wgrad_desc)))
                 if l.dx is not None and l.kind != "lin":
                     need = max(need, L.load().disyolo_bn_act_bwd_workspace(B * l.Ho * l.Wo, l.cout))
-            need = max(need, L.load().disyolo_conv_first_wgrad_workspace(B, S, S, 32))
+            if not l1.lock:
+                import ctypes
+                need = max(need, L.load().disyolo_conv2d_wgrad_workspace(ctypes.byref(self._wgrad1_desc)))
             self.ws.get(int(need))
             self.ws_aux.get(int(need))
         self.ws.get(int(max(L.load().disyolo_detect_workspace(B, S, self.num_class), 1 << 20)))
@@ -610,7 +615,11 @@ class YOLONet(object):
                 L.lane_sync(0, 1)
                 L.set_lane(1)
             if l.idx == 1:
-                L.conv_first_wgrad(self.images, l.dx, l.dw, self.ws_aux)
+                # first layer through the same MFMA kernel: bf16 image padded to 8 channels,
+                # K = 9*8 rows of which 27 are real
+                L.image_pad8(self.images, self._img8)
+                L.conv2d_wgrad(self._wgrad1_desc, l.dx, l.cout, self._dw8, self.ws_aux)
+                L.copy2d_f32(self._dw8, l.dw, 9, 3 * l.cout, 8 * l.cout, 3 * l.cout)
             else:
                 L.conv2d_wgrad(l.wgrad_desc, dx, ld, l.dw, self.ws_aux)
             if side:

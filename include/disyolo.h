@@ -99,6 +99,12 @@ size_t disyolo_conv_first_wgrad_workspace(int B, int H, int W, int Cout);
 int disyolo_conv_first_wgrad(const float* images, const void* dy, float* dw, int B, int H, int W,
                              int Cout, void* workspace, size_t workspace_bytes, void* stream);
 
+/* first-layer helpers for the MFMA weight gradient: images f32 [pixels,3] -> bf16 [pixels,8]
+ * (zero padded channels), and a pitched f32 copy used to drop the padded rows of its result */
+int disyolo_image_pad8(const float* images, void* out_bf16, int64_t pixels, void* stream);
+int disyolo_copy2d_f32(const float* src, float* dst, int rows, int cols, int src_ld, int dst_ld,
+                       void* stream);
+
 /* f32 HWIO master -> packed bf16 operands.  w_fwd [Cout][k*k*Cin] (may be NULL); w_dgrad
  * (may be NULL) [Cin][k*k*cout_pad] with taps flipped and zero columns for co >= Cout, i.e.
  * the forward operand of the data-gradient conv over a dy padded to cout_pad channels. */
