@@ -1,6 +1,12 @@
 """MI355X-native DIS-YOLO hot path: hand-written gfx950 kernels behind a C ABI
 (``include/disyolo.h``, built from ``csrc/``) plus the host-side mirror of the
 reference's ``YOLONet`` / ``Solver`` interface.  Import as ``disyolo_amd``."""
-from . import config  # noqa: F401
+import os as _os
+
+# the two-lane step executor needs its side stream on its own hardware queue even after RCCL
+# has created its streams (ROCm default: 4 queues); read by the HIP runtime at initialisation
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from . import config  # noqa: F401,E402
 
 __all__ = ["config"]

@@ -361,13 +361,16 @@ extern "C" int disyolo_conv2d_wgrad(const disyolo_conv_desc* d, const void* dy, 
   p.out = splits == 1 ? dw : (float*)workspace;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(ceil_div(p.K, 128), ceil_div(p.Cout, bn), splits);
-  constexpr int ST = 4;
-  if (bn == 128)
-    hipLaunchKernelGGL((conv_wgrad_kernel<128, ST>), grid, dim3(256), ST * (8192 + 8192), s, p);
-  else if (bn == 64)
-    hipLaunchKernelGGL((conv_wgrad_kernel<64, ST>), grid, dim3(256), ST * (8192 + 4096), s, p);
-  else
-    hipLaunchKernelGGL((conv_wgrad_kernel<32, ST>), grid, dim3(256), ST * (8192 + 4096), s, p);
+  // pipeline depth: d->tile (1..3 -> 2..4 stages) overrides the default (tuning)
+  const int st = (d->tile >= 1 && d->tile <= 3) ? d->tile + 1 : 3;
+#define DY_WG(BNV, YB)                                                                                   \
+  if (st == 2) hipLaunchKernelGGL((conv_wgrad_kernel<BNV, 2>), grid, dim3(256), 2 * (8192 + YB), s, p);      \
+  else if (st == 3) hipLaunchKernelGGL((conv_wgrad_kernel<BNV, 3>), grid, dim3(256), 3 * (8192 + YB), s, p); \
+  else hipLaunchKernelGGL((conv_wgrad_kernel<BNV, 4>), grid, dim3(256), 4 * (8192 + YB), s, p);
+  if (bn == 128) { DY_WG(128, 8192) }
+  else if (bn == 64) { DY_WG(64, 4096) }
+  else { DY_WG(32, 4096) }
+#undef DY_WG
   DY_CHECK_LAUNCH();
   if (splits > 1) {
     const int64_t n = (int64_t)p.K * p.Cout;

@@ -94,14 +94,23 @@ extern "C" int disyolo_cmdlist_end(void) {
   return DISYOLO_OK;
 }
 extern "C" int disyolo_cmdlist_size(void* l) { return l ? (int)((CmdList*)l)->cmds.size() : DISYOLO_E_ARG; }
+extern "C" void* disyolo_cmdlist_side_stream(void* l) { return l ? (void*)((CmdList*)l)->side : nullptr; }
+
 extern "C" int disyolo_cmdlist_run(void* l, int first, int last, void* stream) {
+  return disyolo_cmdlist_run_ex(l, first, last, stream, 3);
+}
+
+// flags: bit 0 = fork (side lane first waits for the caller's stream), bit 1 = join (the
+// caller's stream finally waits for the side lane).  A step replayed in several ranges forks
+// in the first and joins in the last, so the lanes keep running across the cuts.
+extern "C" int disyolo_cmdlist_run_ex(void* l, int first, int last, void* stream, int flags) {
   DY_REQUIRE(l && !g_rec, "cmdlist_run: null list or called while recording");
   CmdList* c = (CmdList*)l;
   DY_REQUIRE(first >= 0 && last <= (int)c->cmds.size() && first <= last, "cmdlist_run: bad range [%d,%d)", first, last);
   hipStream_t lanes[2] = {(hipStream_t)stream, c->side};
   const bool side = c->uses_side;
-  if (side) {
-    DY_REQUIRE(c->side, "cmdlist_run: side stream unavailable");
+  if (side) DY_REQUIRE(c->side, "cmdlist_run: side stream unavailable");
+  if (side && (flags & 1)) {
     // every replayed range is self-contained: the side lane starts after the caller's prior
     // work and is joined back before returning
     if (hipEventRecord(c->ev_fork, lanes[0]) != hipSuccess || hipStreamWaitEvent(lanes[1], c->ev_fork, 0) != hipSuccess) {
@@ -121,7 +130,7 @@ extern "C" int disyolo_cmdlist_run(void* l, int first, int last, void* stream) {
       }
     }
   }
-  if (side) {
+  if (side && (flags & 2)) {
     if (hipEventRecord(c->ev_join, lanes[1]) != hipSuccess || hipStreamWaitEvent(lanes[0], c->ev_join, 0) != hipSuccess) {
       disyolo_set_error("cmdlist_run: join failed");
       return DISYOLO_E_HIP;

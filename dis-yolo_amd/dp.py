@@ -14,6 +14,7 @@ them and applies the 1/world_size scale inside the Adam kernel.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -61,23 +62,48 @@ class GradientAllReduce:
         for (_, o, c), (_, o2, _) in zip(spans, spans[1:]):
             assert o + c == o2, "arena must be contiguous in layer order"
         self.buckets = plan_buckets(spans, int(bucket_mb * (1 << 20) / 4))
-        self.by_trigger = {t: (o, c) for t, o, c in self.buckets}
+        # a bucket is final when every layer whose slice lies inside it has enqueued its weight
+        # gradient -- the backward pass need not visit layers in strictly descending order
+        self.bucket_of = {}
+        self.members = []
+        for bi, (_, bo, bc) in enumerate(self.buckets):
+            mem = {idx for idx, o, c in spans if bo <= o and o + c <= bo + bc}
+            self.members.append(mem)
+            for idx in mem:
+                self.bucket_of[idx] = bi
+        assert sum(len(m) for m in self.members) == len(spans)
+        self.by_trigger = {t: (o, c) for t, o, c in self.buckets}   # kept for introspection
         self.tail = (net.n_decay, net.n_params - net.n_decay)   # gamma/beta gradients
         self.works = []
+        self._done = [set() for _ in self.buckets]
 
     def begin_step(self) -> None:
         self.works = []
+        self._done = [set() for _ in self.buckets]
+
+    def completes_bucket(self, layer) -> Optional[int]:
+        """record that `layer` is done; returns the bucket index this completes, if any"""
+        bi = self.bucket_of.get(layer.idx)
+        if bi is None:
+            return None
+        self._done[bi].add(layer.idx)
+        return bi if self._done[bi] == self.members[bi] else None
+
+    def fire(self, bi: int) -> None:
+        _, o, c = self.buckets[bi]
+        if os.environ.get("DISYOLO_DP_DRY") == "1":   # timing probe: protocol without the collective
+            return
+        self.works.append(dist.all_reduce(self.net.grad_arena[o:o + c], op=dist.ReduceOp.SUM, group=self.pg,
+                                          async_op=True))
 
     def on_layer_done(self, layer) -> None:
-        span = self.by_trigger.get(layer.idx)
-        if span is not None:
-            o, c = span
-            self.works.append(dist.all_reduce(self.net.grad_arena[o:o + c], op=dist.ReduceOp.SUM, group=self.pg,
-                                              async_op=True))
+        bi = self.completes_bucket(layer)
+        if bi is not None:
+            self.fire(bi)
 
     def finish(self) -> None:
         o, c = self.tail
-        if c > 0:
+        if c > 0 and os.environ.get("DISYOLO_DP_DRY") != "1":
             self.works.append(dist.all_reduce(self.net.grad_arena[o:o + c], op=dist.ReduceOp.SUM, group=self.pg,
                                               async_op=True))
         for w in self.works:

@@ -97,6 +97,8 @@ _SIGS = {
     "disyolo_cmdlist_set_lane": (C.c_int, [C.c_int]),
     "disyolo_cmdlist_sync": (C.c_int, [C.c_int, C.c_int]),
     "disyolo_cmdlist_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "disyolo_cmdlist_run_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "disyolo_cmdlist_side_stream": (C.c_void_p, [C.c_void_p]),
     "disyolo_l2_workspace": (C.c_size_t, [C.c_int64]),
     "disyolo_l2_loss": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
@@ -187,9 +189,14 @@ class CmdList:
     def size(self) -> int:
         return load().disyolo_cmdlist_size(self.h)
 
-    def run(self, first: int = 0, last: Optional[int] = None) -> None:
+    def run(self, first: int = 0, last: Optional[int] = None, fork: bool = True, join: bool = True) -> None:
         last = self.size() if last is None else last
-        _check(load().disyolo_cmdlist_run(self.h, first, last, _stream()), "cmdlist_run")
+        _check(load().disyolo_cmdlist_run_ex(self.h, first, last, _stream(), (1 if fork else 0) | (2 if join else 0)),
+               "cmdlist_run")
+
+    def side_stream(self, device) -> "torch.cuda.Stream":
+        """the side lane as a torch stream (to order an RCCL collective after it)"""
+        return torch.cuda.ExternalStream(load().disyolo_cmdlist_side_stream(self.h), device=device)
 
 
 def same_pads(size: int, k: int, s: int):

@@ -143,6 +143,7 @@ class YOLONet(object):
         L.load()
         self.ws = L.Workspace(self.device)
         self.ws_aux = L.Workspace(self.device)      # scratch of the side lane (weight gradients)
+        self.ws_det = L.Workspace(self.device)      # scratch of the detection filter (either lane)
         # lock map: stage 1 = conv1-52 locked (shipped source), stage 2 = all trainable
         self.lock = dict(lock) if lock is not None else {i: (stage == 1 and i <= 52) for i in range(1, 83)}
         self.layers = build_topology(self.num_class, self.k)
@@ -153,6 +154,7 @@ class YOLONet(object):
         self._prog_marks = []   # [(command index, layer)] all-reduce trigger points
         self._graph = None      # hipGraph of the recorded step (single GPU)
         self._pack_table = None
+        self._side_stream = None
         self.use_side_lane = os.environ.get("DISYOLO_SIDE_LANE", "1") != "0"
         self._init_params(seed, xavier_locked)
         self._plan(self.batchsize, self.image_size)
@@ -379,7 +381,7 @@ class YOLONet(object):
                 need = max(need, L.load().disyolo_conv2d_wgrad_workspace(ctypes.byref(self._wgrad1_desc)))
             self.ws.get(int(need))
             self.ws_aux.get(int(need))
-        self.ws.get(int(max(L.load().disyolo_detect_workspace(B, S, self.num_class), 1 << 20)))
+        self.ws_det.get(int(max(L.load().disyolo_detect_workspace(B, S, self.num_class), 1 << 20)))
         self._build_dgrad_descs()
         self.refresh_weights()
 
@@ -414,9 +416,28 @@ class YOLONet(object):
                 L.bn_fold(l.gamma, l.beta, l.mm, l.mv, cfg.BN_EPSILON, l.scale, l.shift)
 
     # ------------------------------------------------------------------ forward
+    # layers that only feed a detection head: in a recorded step they run on the side lane while
+    # the trunk continues (58/59 after 57, 66/67 after 65, 74/75 after 73)
+    HEAD_BRANCH = {58: 57, 66: 65, 74: 73}
+    HEAD_LAYERS = (58, 59, 66, 67, 74, 75)
+
     def _forward_layers(self, is_training: bool) -> None:
         B = self.B
         for l in self.layers:
+            if self.use_side_lane:
+                if l.idx in self.HEAD_BRANCH:
+                    L.lane_sync(0, 1)        # the branch point's output is ready on the main lane
+                    L.set_lane(1)
+                elif l.idx in (60, 68, 76):
+                    L.set_lane(0)
+            self._forward_layer(l, is_training)
+        if self.use_side_lane:
+            L.set_lane(0)
+            L.lane_sync(1, 0)
+
+    def _forward_layer(self, l, is_training: bool) -> None:
+        B = self.B
+        if True:
             train_bn = is_training and self.training and (not l.lock) and l.kind != "lin"
             M = B * l.Ho * l.Wo
             res = self.by_idx[l.shortcut].act if l.shortcut is not None else None
@@ -431,7 +452,7 @@ class YOLONet(object):
                     if not l.lock and self.training:
                         L.bn_fold(l.gamma, l.beta, l.mm, l.mv, cfg.BN_EPSILON, l.scale, l.shift)
                     L.conv_first_fwd(self.images, l.w, l.scale, l.shift, l.act, alpha=cfg.ALPHA)
-                continue
+                return
             if l.kind == "lin":
                 L.conv2d_fwd(l.desc)
             elif train_bn:
@@ -453,7 +474,7 @@ class YOLONet(object):
     def _detect(self, det_thresh: float) -> None:
         L.detect(self.by_idx[75].act, self.by_idx[67].act, self.by_idx[59].act, self.B, self.S, self.num_class,
                  self.anchors.reshape(-1), self.clip_window, float(det_thresh), cfg.IOU_THRESHOLD, cfg.MAX_DETECTION,
-                 self.detections, self.det_count, self.ws)
+                 self.detections, self.det_count, self.ws_det)
 
     def _set_inputs(self, images, clip_window) -> None:
         images = torch.as_tensor(images)
@@ -557,19 +578,28 @@ class YOLONet(object):
         """forward (training mode) + detections + both losses and their gradients wrt the
         head logits / score maps (yolo/yolo3_net_pos.py:59-60)."""
         self._forward_layers(True)
-        self._detect(det_thresh)
         heads = [self.by_idx[75], self.by_idx[67], self.by_idx[59]]
-        L.yolo_loss([h.act for h in heads], self.labels, self.true_boxes, cfg.MAX_BOX_PER_IMAGE, self.B, self.S,
-                    self.num_class, self.anchors.reshape(-1), cfg.IGNORE_THRESH,
-                    (self.object_scale, self.noobject_scale, self.class_scale, self.coord_scale),
-                    [h.dx for h in heads], self.losses, self.ws)
+        side = self.use_side_lane
+        if side:
+            # detection filter -> RoI selection -> mask loss only feed the mask subnet's backward:
+            # side lane, while the main lane does the YOLO loss and the heads' backward
+            L.lane_sync(0, 1)
+            L.set_lane(1)
+        self._detect(det_thresh)
         Sm = self.S // 2
         L.mask_rois(self.detections, cfg.MAX_DETECTION, self.true_boxes, cfg.MAX_BOX_PER_IMAGE, self.perm_det,
                     self.perm_gt, self.B, Sm, cfg.MASK_ROI_DET, cfg.MASK_ROI_GT, cfg.MASK_ROI_IOU, self.rois,
                     self.roi_count)
         m = self.by_idx[82]
         L.psroi_loss(m.act, self.true_masks, cfg.MAX_BOX_PER_IMAGE, self.rois, self.roi_count, self.B, Sm, self.k,
-                     self.mask_scale, m.dx, self.mask_loss, self.ws)
+                     self.mask_scale, m.dx, self.mask_loss, self.ws_aux if side else self.ws)
+        if side:
+            L.set_lane(0)
+        L.yolo_loss([h.act for h in heads], self.labels, self.true_boxes, cfg.MAX_BOX_PER_IMAGE, self.B, self.S,
+                    self.num_class, self.anchors.reshape(-1), cfg.IGNORE_THRESH,
+                    (self.object_scale, self.noobject_scale, self.class_scale, self.coord_scale),
+                    [h.dx for h in heads], self.losses, self.ws)
+        self._mask_loss_pending = side
 
     def _accumulate_into(self, tgt: Layer, desc_kw: dict, dx: torch.Tensor, cin_eff: int, k: int, in_div: int) -> None:
         """one data-gradient conv writing (first contribution) or accumulating into tgt.grad"""
@@ -587,14 +617,21 @@ class YOLONet(object):
         B = self.B
         for l in self.layers:
             l.grad_set = False
-        for l in reversed(self.layers):
+        # any topological order of the reversed graph is valid.  The three detection heads
+        # (75,74 / 67,66 / 59,58) depend on the YOLO loss only, so they go first while the side
+        # lane still runs the detection filter and the mask loss; the mask subnet follows.
+        heads = [self.by_idx[i] for i in (75, 74, 67, 66, 59, 58)]
+        rest = [l for l in reversed(self.layers) if l.idx not in self.HEAD_LAYERS]
+        for l in heads + rest:
+            if l.idx == 82 and getattr(self, "_mask_loss_pending", False):
+                L.lane_sync(1, 0)          # dscore comes from the side lane
+                self._mask_loss_pending = False
             if l.lock:
                 # locked layers still pass gradients through their residual add only in
                 # stage 2; in stage 1 nothing upstream is trainable
                 continue
             M = B * l.Ho * l.Wo
             if l.kind == "lin":
-                L.colsum(l.dx, l.dbias, M, L.GRAD_LD, l.cout, self.ws)
                 dx, ld = l.dx, L.GRAD_LD
             else:
                 if not l.grad_set:
@@ -614,6 +651,8 @@ class YOLONet(object):
             if side:
                 L.lane_sync(0, 1)
                 L.set_lane(1)
+            if l.kind == "lin":
+                L.colsum(l.dx, l.dbias, M, L.GRAD_LD, l.cout, self.ws_aux)   # bias gradient
             if l.idx == 1:
                 # first layer through the same MFMA kernel: bf16 image padded to 8 channels,
                 # K = 9*8 rows of which 27 are real
@@ -678,11 +717,15 @@ class YOLONet(object):
             if self.n_decay:
                 L.l2_loss(self.arena, self.n_decay, self.l2, self.reg_loss, self.ws)
             if self.dp is not None:
-                triggers = self.dp.by_trigger
+                self.dp.begin_step()
+
                 def mark(l):
-                    if l.idx in triggers:
-                        L.lane_sync(1, 0)          # the bucket's weight gradients are on the side lane
-                        marks.append((prog.size(), l))
+                    # weight / bias gradients are produced on the side lane: the bucket's
+                    # all-reduce is ordered after that lane only (run_program), the main lane
+                    # is never stalled by the exchange
+                    bi = self.dp.completes_bucket(l)
+                    if bi is not None:
+                        marks.append((prog.size(), bi))
                 self.backward(mark)
             else:
                 self.backward()
@@ -716,18 +759,22 @@ class YOLONet(object):
         if self._graph is not None:
             self._graph.replay()
             return
-        if self.dp is None:
+        if self.dp is None or os.environ.get("DISYOLO_DP_NOSEG") == "1":
             self._prog.run()
             return
         self.dp.begin_step()
-        pos = 0
-        for idx, layer in self._prog_marks:
-            self._prog.run(pos, idx)
-            self.dp.on_layer_done(layer)
+        if self._side_stream is None:
+            self._side_stream = self._prog.side_stream(self.device)
+        pos, first = 0, True
+        for idx, bucket in self._prog_marks:
+            self._prog.run(pos, idx, fork=first, join=False)
+            first = False
+            with torch.cuda.stream(self._side_stream if self.use_side_lane else torch.cuda.current_stream()):
+                self.dp.fire(bucket)
             pos = idx
-        self._prog.run(pos, self._bwd_end)
+        self._prog.run(pos, self._bwd_end, fork=first, join=True)
         self.dp.finish()
-        self._prog.run(self._bwd_end, None)
+        self._prog.run(self._bwd_end, None, fork=False, join=False)
 
     def train_step(self, batch: Optional[Dict] = None, det_thresh: float = cfg.OBJ_THRESHOLD,
                    want_loss: bool = True):

@@ -244,6 +244,11 @@ int disyolo_cmdlist_size(void* list);
 int disyolo_cmdlist_set_lane(int lane);
 int disyolo_cmdlist_sync(int from_lane, int to_lane);
 int disyolo_cmdlist_run(void* list, int first, int last, void* stream);
+/* same with explicit fork/join control (flags bit 0 = fork at the start, bit 1 = join at the
+ * end) for a step replayed in several ranges, and the side lane's hipStream_t so a caller can
+ * order other work (an RCCL all-reduce) after the side lane only */
+int disyolo_cmdlist_run_ex(void* list, int first, int last, void* stream, int flags);
+void* disyolo_cmdlist_side_stream(void* list);
 
 #ifdef __cplusplus
 }
