@@ -262,9 +262,19 @@ def main():
             dom = max(summ, key=lambda k: summ[k]["ms_total"])
             r = summ[dom]
             achieved = r["flops_total"] / (r["ms_total"] * 1e-3) / 1e12
+            traffic, traffic_src = None, None
+            try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc, see the file's "method")
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")))
+                key = dom.replace(",", ", ")
+                if key in pmc["kernels"]:
+                    traffic = pmc["kernels"][key]["hbm_mb_per_launch_corrected"] * 1e6
+                    traffic_src = "profiles/r01e_pmc_traffic.json"
+            except Exception:
+                pass
             out["roofline"] = {"bound": "mfma", "kernel": dom, "timed_with": "HIP events, %d eager steps of the same workload" % args.steps, "achieved": round(achieved, 1),
                                "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                               "traffic": None,
+                               "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                               "traffic_source": traffic_src,
                                "flops_per_launch": round(r["flops_total"] / r["launches"] / 1e9, 3),
                                "flops_per_launch_unit": "GFLOP (algorithmic, 2*M*N*K averaged over this kernel's launches)",
                                "avg_launch_us": round(r["ms_total"] / r["launches"] * 1e3, 2),

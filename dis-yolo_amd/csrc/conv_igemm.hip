@@ -549,13 +549,24 @@ extern "C" int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d) {
   return ceil_div(M, bm);
 }
 
-extern "C" int disyolo_conv2d_tile(const disyolo_conv_desc* d, int* bm, int* bn) {
+// stages per (tile id, BK, variant): keep in sync with DY_TILE in dispatch()
+static int tile_stages(int id, bool bk64, int variant) {
+  static const int tab[9][4] = {{0, 0, 0, 0}, {2, 3, 3, 4}, {3, 2, 4, 3}, {2, 3, 4, 3}, {3, 2, 4, 3},
+                                {3, 2, 4, 3}, {3, 2, 4, 3}, {3, 2, 4, 3}, {2, 3, 3, 4}};
+  return tab[id][(bk64 ? 0 : 2) + (variant ? 1 : 0)];
+}
+
+extern "C" int disyolo_conv2d_tile(const disyolo_conv_desc* d, int* bm, int* bn, int* bk, int* stages) {
   if (!d) return DISYOLO_E_ARG;
-  const int id = pick_tile(d, d->B * d->Ho * d->Wo) & 0xff;
+  const int sel = pick_tile(d, d->B * d->Ho * d->Wo);
+  const int id = sel & 0xff;
+  const bool bk64 = (d->C0 % 64 == 0) && (d->C1 % 64 == 0) && !(sel & 0x100);
   for (const TileCfg& t : kTiles)
     if (t.id == id) {
       if (bm) *bm = t.bm;
       if (bn) *bn = t.bn;
+      if (bk) *bk = bk64 ? 64 : 32;
+      if (stages) *stages = tile_stages(id, bk64, (sel >> 9) & 1);
       return id;
     }
   return DISYOLO_E_ARG;

@@ -46,7 +46,7 @@ _SIGS = {
     "disyolo_last_error": (C.c_char_p, []),
     "disyolo_conv2d_stats_rows": (C.c_int, [C.POINTER(ConvDesc)]),
     "disyolo_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
-    "disyolo_conv2d_tile": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "disyolo_conv2d_tile": (C.c_int, [C.POINTER(ConvDesc)] + [C.POINTER(C.c_int)] * 4),
     "disyolo_conv_first_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "disyolo_conv2d_wgrad_workspace": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "disyolo_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
@@ -273,19 +273,23 @@ def conv_flops(d: ConvDesc) -> float:
     return 2.0 * d.B * d.Ho * d.Wo * d.Cout * K / float(d.in_div * d.in_div)
 
 
+_WAVES = {1: (2, 2), 2: (2, 2), 3: (2, 2), 4: (4, 1), 5: (4, 1), 6: (2, 2), 7: (4, 1), 8: (4, 2)}
+
+
 def conv2d_tile(d: ConvDesc):
-    bm, bn = C.c_int(0), C.c_int(0)
-    tid = load().disyolo_conv2d_tile(C.byref(d), C.byref(bm), C.byref(bn))
+    """(tile id, BM, BN, BK, stages) of the conv_igemm_kernel instance the launcher will pick"""
+    bm, bn, bk, st = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    tid = load().disyolo_conv2d_tile(C.byref(d), C.byref(bm), C.byref(bn), C.byref(bk), C.byref(st))
     if tid < 0:
         raise DisyoloError("conv2d_tile: bad descriptor")
-    return tid, bm.value, bn.value
+    return tid, bm.value, bn.value, bk.value, st.value
 
 
 def conv2d_fwd(d: ConvDesc) -> None:
     if TIMER is not None:
         if not hasattr(d, "_tname"):
-            _, bm, bn = conv2d_tile(d)
-            d._tname = "conv_igemm_kernel<%d,%d>" % (bm, bn)
+            tid, bm, bn, bk, st = conv2d_tile(d)
+            d._tname = "conv_igemm_kernel<%d,%d,%d,%d,%d,%d>" % ((bm, bn) + _WAVES[tid] + (bk, st))
         TIMER.run(d._tname, conv_flops(d), lambda: _check(load().disyolo_conv2d_fwd(C.byref(d), _stream()),
                                                            "conv2d_fwd"))
         return
@@ -304,7 +308,7 @@ def conv2d_wgrad(d: ConvDesc, dy, dy_ld: int, dw, ws: Workspace) -> None:
     need = load().disyolo_conv2d_wgrad_workspace(C.byref(d))
     buf = ws.get(need)
     if TIMER is not None:
-        name = "conv_wgrad_kernel<%d>" % (128 if d.Cout > 64 else (64 if d.Cout > 32 else 32))
+        name = "conv_wgrad_kernel<%d,3>" % (128 if d.Cout > 64 else (64 if d.Cout > 32 else 32))
         TIMER.run(name, conv_flops(d), lambda: _check(
             load().disyolo_conv2d_wgrad(C.byref(d), _p(dy), dy_ld, _p(dw), _p(buf), buf.numel(), _stream()),
             "conv2d_wgrad"))

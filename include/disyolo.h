@@ -77,8 +77,9 @@ typedef struct disyolo_conv_desc {
 int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d);
 int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream);
 /* tile configuration the launcher picks for this descriptor: returns its id (> 0) and the
- * block tile (pixels x channels); used by bench.py to attribute time per kernel variant */
-int disyolo_conv2d_tile(const disyolo_conv_desc* d, int* bm, int* bn);
+ * block tile (pixels x channels), K depth and pipeline stages -- the template arguments of the
+ * conv_igemm_kernel instance that will run; bench.py attributes time per instance with it */
+int disyolo_conv2d_tile(const disyolo_conv_desc* d, int* bm, int* bn, int* bk, int* stages);
 
 /* first layer (Cin=3, k=3, s=1; yolo/yolo3_net_pos.py:159): f32 NHWC image in, exact f32
  * FMA with the f32 HWIO weights, folded BN + leaky, bf16 out. */

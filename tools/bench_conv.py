@@ -66,7 +66,7 @@ for key, idxs in sorted(shapes.items(), key=lambda kv: -kv[0][0]):
         row.append("%9.1f" % (fl / dt / 1e12))
     d = L.make_conv_desc(x0, w, y, k, s, x1=x1, scale=sc, shift=sh, leaky=True, tile=0)
     dta = timeit(d)
-    tid, bm, bn = L.conv2d_tile(d)
+    tid = L.conv2d_tile(d)[0]
     tot_auto += dta * len(idxs)
     tot_best += min(best, dta) * len(idxs)
     print("%-34s %-10s %8.2f | " % (str(key[:5]) + ("F" if fused else ""), ("x%d" % len(idxs)), fl / 1e9) + " ".join(row) +
