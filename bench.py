@@ -151,6 +151,10 @@ def main():
                          "PS-RoI mask assembly, hipGraph replay), reported as a secondary line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--pipeline", default="auto", choices=("auto", "on", "off"),
+                    help="cross-step software pipeline of the locked backbone (stage 1): each step computes the "
+                         "backbone forward of the NEXT batch on a third lane while it runs heads/losses/backward/Adam "
+                         "of the current one (bit-identical results, but measured slower: auto = off)")
     ap.add_argument("--force-dp", action="store_true",
                     help="initialise RCCL and run the bucketed gradient all-reduce path even with one rank (self-test)")
     ap.add_argument("--mode", default="auto", choices=("auto", "graph", "program", "eager"),
@@ -210,8 +214,15 @@ def main():
             step()
         torch.cuda.synchronize()
         L.TIMER = None
+    # measured: the third lane's big conv kernels contend with the backward pass instead of filling
+    # its bubbles (958-1387 vs 1404 img/s without), so "auto" leaves the pipeline off
+    pipe = args.stage == 1 and mode == "program" and args.pipeline == "on"
+    if args.pipeline == "on" and not pipe:
+        raise SystemExit("--pipeline on needs --stage 1 and --mode program")
     if mode != "eager":
-        net.build_program(graph=(mode == "graph"))
+        net.build_program(graph=(mode == "graph"), pipeline_backbone=pipe)
+        if pipe:
+            net.prime_pipeline()       # backbone of the first batch, outside the timed region
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -245,7 +256,7 @@ def main():
                        "images_per_gpu": B, "global_batch": B * world, "image_size": S,
                        "stage": "1: conv1-52 locked (shipped reference source)" if args.stage == 1 else
                                 "2: all 82 layers trainable",
-                       "parallelism": "dp%d" % world, "rccl_buckets": (len(net.dp.buckets) + 1) if net.dp else 0, "optimizer": "adam(tf-form) lr=1e-4", "step_driver": mode,
+                       "parallelism": "dp%d" % world, "rccl_buckets": (len(net.dp.buckets) + 1) if net.dp else 0, "optimizer": "adam(tf-form) lr=1e-4", "step_driver": mode, "backbone_pipeline": bool(args.stage == 1 and mode == "program" and args.pipeline == "on"),
                        "final_total_loss": round(loss, 4)},
             "model_flops": {"train_gflop_per_image": round(train_gflop, 1),
                             "achieved_tflops_per_gpu": round(train_gflop * value / world / 1e3, 1),

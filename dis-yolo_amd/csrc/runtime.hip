@@ -1,3 +1,4 @@
+#include <stdlib.h>
 #include <vector>
 #include "common.h"
 #include "runtime.h"
@@ -10,11 +11,12 @@ struct Cmd {
   int kind, lane, from, to;
   hipEvent_t ev;
 };
+constexpr int NLANES = 3;   // lane 0 = the caller's stream, lanes 1.. = side streams owned by the list
 struct CmdList {
   std::vector<Cmd> cmds;
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool uses_side = false;
+  hipStream_t side[NLANES] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[NLANES] = {nullptr, nullptr, nullptr};
+  bool uses[NLANES] = {true, false, false};
 };
 thread_local CmdList* g_rec = nullptr;
 thread_local int g_lane = 0;
@@ -39,17 +41,22 @@ __global__ __launch_bounds__(256) void add_bf16_kernel(const uint4* src, uint4* 
 bool dy_recording() { return g_rec != nullptr; }
 int dy_record(std::function<int(void*)> fn) {
   g_rec->cmds.push_back(Cmd{std::move(fn), 0, g_lane, 0, 0, nullptr});
-  if (g_lane) g_rec->uses_side = true;
+  g_rec->uses[g_lane] = true;
   return DISYOLO_OK;
 }
 
 extern "C" void* disyolo_cmdlist_create(void) {
   CmdList* c = new CmdList();
-  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
-    c->side = nullptr;  // no device (CPU-only build check): lists can still be recorded, not run
-  }
+  bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+  // lane 2 carries work that must only fill the other lanes' bubbles (the next step's backbone):
+  // lowest stream priority
+  int least = 0, greatest = 0;
+  if (ok) ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+  for (int i = 1; i < NLANES && ok; ++i)
+    ok = hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking, (i == 2 && getenv("DISYOLO_LANE2_LOW")) ? least : 0) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok)  // no device (CPU-only build check): lists can still be recorded, not run
+    for (int i = 1; i < NLANES; ++i) c->side[i] = nullptr;
   return c;
 }
 extern "C" void disyolo_cmdlist_destroy(void* l) {
@@ -58,8 +65,10 @@ extern "C" void disyolo_cmdlist_destroy(void* l) {
   for (Cmd& k : c->cmds)
     if (k.ev) (void)hipEventDestroy(k.ev);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-  if (c->side) (void)hipStreamDestroy(c->side);
+  for (int i = 1; i < NLANES; ++i) {
+    if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+    if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
+  }
   delete c;
 }
 extern "C" int disyolo_cmdlist_begin(void* l) {
@@ -71,13 +80,13 @@ extern "C" int disyolo_cmdlist_begin(void* l) {
 // lane for the following launches of the recording thread (no-op when not recording: the
 // per-call path runs everything on the caller's stream, which is trivially ordered)
 extern "C" int disyolo_cmdlist_set_lane(int lane) {
-  DY_REQUIRE(lane == 0 || lane == 1, "cmdlist_set_lane: lane must be 0 or 1");
+  DY_REQUIRE(lane >= 0 && lane < NLANES, "cmdlist_set_lane: lane must be 0..%d", NLANES - 1);
   if (g_rec) g_lane = lane;
   return DISYOLO_OK;
 }
 // lane `to` waits for everything recorded so far on lane `from` (no-op when not recording)
 extern "C" int disyolo_cmdlist_sync(int from, int to) {
-  DY_REQUIRE((from == 0 || from == 1) && (to == 0 || to == 1) && from != to, "cmdlist_sync: bad lanes");
+  DY_REQUIRE(from >= 0 && from < NLANES && to >= 0 && to < NLANES && from != to, "cmdlist_sync: bad lanes");
   if (!g_rec) return DISYOLO_OK;
   hipEvent_t ev;
   if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
@@ -85,7 +94,7 @@ extern "C" int disyolo_cmdlist_sync(int from, int to) {
     return DISYOLO_E_HIP;
   }
   g_rec->cmds.push_back(Cmd{nullptr, 1, 0, from, to, ev});
-  g_rec->uses_side = true;
+  g_rec->uses[from] = g_rec->uses[to] = true;
   return DISYOLO_OK;
 }
 extern "C" int disyolo_cmdlist_end(void) {
@@ -94,7 +103,7 @@ extern "C" int disyolo_cmdlist_end(void) {
   return DISYOLO_OK;
 }
 extern "C" int disyolo_cmdlist_size(void* l) { return l ? (int)((CmdList*)l)->cmds.size() : DISYOLO_E_ARG; }
-extern "C" void* disyolo_cmdlist_side_stream(void* l) { return l ? (void*)((CmdList*)l)->side : nullptr; }
+extern "C" void* disyolo_cmdlist_side_stream(void* l) { return l ? (void*)((CmdList*)l)->side[1] : nullptr; }
 
 extern "C" int disyolo_cmdlist_run(void* l, int first, int last, void* stream) {
   return disyolo_cmdlist_run_ex(l, first, last, stream, 3);
@@ -107,15 +116,25 @@ extern "C" int disyolo_cmdlist_run_ex(void* l, int first, int last, void* stream
   DY_REQUIRE(l && !g_rec, "cmdlist_run: null list or called while recording");
   CmdList* c = (CmdList*)l;
   DY_REQUIRE(first >= 0 && last <= (int)c->cmds.size() && first <= last, "cmdlist_run: bad range [%d,%d)", first, last);
-  hipStream_t lanes[2] = {(hipStream_t)stream, c->side};
-  const bool side = c->uses_side;
-  if (side) DY_REQUIRE(c->side, "cmdlist_run: side stream unavailable");
-  if (side && (flags & 1)) {
-    // every replayed range is self-contained: the side lane starts after the caller's prior
-    // work and is joined back before returning
-    if (hipEventRecord(c->ev_fork, lanes[0]) != hipSuccess || hipStreamWaitEvent(lanes[1], c->ev_fork, 0) != hipSuccess) {
-      disyolo_set_error("cmdlist_run: fork failed");
-      return DISYOLO_E_HIP;
+  hipStream_t lanes[NLANES];
+  lanes[0] = (hipStream_t)stream;
+  for (int i = 1; i < NLANES; ++i) {
+    lanes[i] = c->side[i];
+    if (c->uses[i]) DY_REQUIRE(c->side[i], "cmdlist_run: side stream unavailable");
+  }
+  if (flags & 1) {
+    bool any = false;
+    for (int i = 1; i < NLANES; ++i) any = any || c->uses[i];
+    if (any) {
+      if (hipEventRecord(c->ev_fork, lanes[0]) != hipSuccess) {
+        disyolo_set_error("cmdlist_run: fork failed");
+        return DISYOLO_E_HIP;
+      }
+      for (int i = 1; i < NLANES; ++i)
+        if (c->uses[i] && hipStreamWaitEvent(lanes[i], c->ev_fork, 0) != hipSuccess) {
+          disyolo_set_error("cmdlist_run: fork failed");
+          return DISYOLO_E_HIP;
+        }
     }
   }
   for (int i = first; i < last; ++i) {
@@ -130,11 +149,13 @@ extern "C" int disyolo_cmdlist_run_ex(void* l, int first, int last, void* stream
       }
     }
   }
-  if (side && (flags & 2)) {
-    if (hipEventRecord(c->ev_join, lanes[1]) != hipSuccess || hipStreamWaitEvent(lanes[0], c->ev_join, 0) != hipSuccess) {
-      disyolo_set_error("cmdlist_run: join failed");
-      return DISYOLO_E_HIP;
-    }
+  if (flags & 2) {
+    for (int i = 1; i < NLANES; ++i)
+      if (c->uses[i] && (hipEventRecord(c->ev_join[i], lanes[i]) != hipSuccess ||
+                         hipStreamWaitEvent(lanes[0], c->ev_join[i], 0) != hipSuccess)) {
+        disyolo_set_error("cmdlist_run: join failed");
+        return DISYOLO_E_HIP;
+      }
   }
   return DISYOLO_OK;
 }

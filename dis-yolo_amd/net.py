@@ -155,6 +155,7 @@ class YOLONet(object):
         self._graph = None      # hipGraph of the recorded step (single GPU)
         self._pack_table = None
         self._side_stream = None
+        self._progs = None      # [parity] -> (list, marks, bwd_end) of the pipelined step
         self.use_side_lane = os.environ.get("DISYOLO_SIDE_LANE", "1") != "0"
         self._init_params(seed, xavier_locked)
         self._plan(self.batchsize, self.image_size)
@@ -313,26 +314,7 @@ class YOLONet(object):
                 has_trainable_upto[l.src] or (l.src_up is not None and has_trainable_upto[l.src_up]))
             if needs_dgrad:
                 l.wdg = torch.zeros(l.cin, l.k * l.k * l.cout_pad, dtype=BF16, device=dev)
-        # descriptors (raw pointers into the buffers above)
-        for l in self.layers:
-            if l.idx == 1:
-                continue
-            x0 = self.by_idx[l.src].act
-            x1 = self.by_idx[l.src_up].act if l.src_up is not None else None
-            res = self.by_idx[l.shortcut].act if l.shortcut is not None else None
-            train_bn = self.training and (not l.lock) and l.kind != "lin"
-            if l.kind == "lin":
-                l.desc = L.make_conv_desc(x0, l.wp, l.act, l.k, l.stride, x1=x1, shift=l.bias, out_f32=True)
-            elif train_bn:
-                d0 = L.make_conv_desc(x0, l.wp, l.raw, l.k, l.stride, x1=x1)
-                l.stats_rows = L.conv2d_stats_rows(d0)
-                l.stats = torch.zeros(l.stats_rows, l.cout, 2, dtype=F32, device=dev)
-                l.desc = L.make_conv_desc(x0, l.wp, l.raw, l.k, l.stride, x1=x1, stats=l.stats)
-            else:
-                l.desc = L.make_conv_desc(x0, l.wp, l.act, l.k, l.stride, x1=x1, scale=l.scale, shift=l.shift,
-                                          residual=res, leaky=True, alpha=cfg.ALPHA)
-            if self.training and not l.lock:
-                l.wgrad_desc = L.make_conv_desc(x0, l.wp, l.act, l.k, l.stride, x1=x1)
+        self._build_descs()
         l1 = self.by_idx[1]
         if self.training and not l1.lock:
             self._img8 = torch.zeros(B, S, S, 8, dtype=BF16, device=dev)
@@ -385,6 +367,65 @@ class YOLONet(object):
         self._build_dgrad_descs()
         self.refresh_weights()
 
+    def _build_descs(self) -> None:
+        """conv descriptors (raw pointers into the activation buffers).  Rebuilt when the
+        pipelined step switches the double-buffered backbone outputs (``_use_parity``)."""
+        dev = self.device
+        for l in self.layers:
+            if l.idx == 1:
+                continue
+            x0 = self.by_idx[l.src].act
+            x1 = self.by_idx[l.src_up].act if l.src_up is not None else None
+            res = self.by_idx[l.shortcut].act if l.shortcut is not None else None
+            train_bn = self.training and (not l.lock) and l.kind != "lin"
+            if l.kind == "lin":
+                l.desc = L.make_conv_desc(x0, l.wp, l.act, l.k, l.stride, x1=x1, shift=l.bias, out_f32=True)
+            elif train_bn:
+                if l.stats is None:
+                    d0 = L.make_conv_desc(x0, l.wp, l.raw, l.k, l.stride, x1=x1)
+                    l.stats_rows = L.conv2d_stats_rows(d0)
+                    l.stats = torch.zeros(l.stats_rows, l.cout, 2, dtype=F32, device=dev)
+                l.desc = L.make_conv_desc(x0, l.wp, l.raw, l.k, l.stride, x1=x1, stats=l.stats)
+            else:
+                l.desc = L.make_conv_desc(x0, l.wp, l.act, l.k, l.stride, x1=x1, scale=l.scale, shift=l.shift,
+                                          residual=res, leaky=True, alpha=cfg.ALPHA)
+            if self.training and not l.lock:
+                l.wgrad_desc = L.make_conv_desc(x0, l.wp, l.act, l.k, l.stride, x1=x1)
+
+    # ---- cross-step software pipeline of the locked backbone (stage 1) -------------------
+    def _backbone_prefix(self) -> int:
+        """number of leading locked layers whose outputs do not depend on trained weights"""
+        p = 0
+        for l in self.layers:
+            if not l.lock:
+                break
+            p = l.idx
+        return p
+
+    def _setup_pipeline(self) -> None:
+        P = self._backbone_prefix()
+        if P < 2 or not self.training:
+            raise L.DisyoloError("the backbone pipeline needs a locked layer prefix (stage 1)")
+        self._pipe_P = P
+        # backbone outputs consumed by the trainable part: two copies each
+        xs = sorted({i for l in self.layers if l.idx > P for i in (l.src, l.src_up, l.shortcut)
+                     if i is not None and 1 <= i <= P})
+        self._xbuf = {i: (self.by_idx[i].act, torch.zeros_like(self.by_idx[i].act)) for i in xs}
+        self._parity = 0
+
+    def _use_parity(self, q: int) -> None:
+        for i, bufs in self._xbuf.items():
+            self.by_idx[i].act = bufs[q]
+        self._build_descs()
+
+    def prime_pipeline(self) -> None:
+        """run the backbone once for the images currently set (fills parity 0); afterwards every
+        train_step consumes that result and computes the backbone of the NEXT images meanwhile"""
+        self._use_parity(0)
+        for l in self.layers[:self._pipe_P]:
+            self._forward_layer(l, True)
+        self._parity = 0
+
     def _build_dgrad_descs(self) -> None:
         """Data-gradient convs: forward kernel over dx with the flipped operand (wdg), pads
         k-1-pad and the transposed gather (in_div = stride)."""
@@ -421,9 +462,11 @@ class YOLONet(object):
     HEAD_BRANCH = {58: 57, 66: 65, 74: 73}
     HEAD_LAYERS = (58, 59, 66, 67, 74, 75)
 
-    def _forward_layers(self, is_training: bool) -> None:
+    def _forward_layers(self, is_training: bool, first: int = 1) -> None:
         B = self.B
         for l in self.layers:
+            if l.idx < first:
+                continue
             if self.use_side_lane:
                 if l.idx in self.HEAD_BRANCH:
                     L.lane_sync(0, 1)        # the branch point's output is ready on the main lane
@@ -574,10 +617,10 @@ class YOLONet(object):
         self.perm_det.copy_(torch.rand(B, cfg.MAX_DETECTION, device=self.device, generator=generator).argsort(dim=1))
         self.perm_gt.copy_(torch.rand(B, cfg.MAX_BOX_PER_IMAGE, device=self.device, generator=generator).argsort(dim=1))
 
-    def compute_losses(self, det_thresh: float = cfg.OBJ_THRESHOLD) -> None:
+    def compute_losses(self, det_thresh: float = cfg.OBJ_THRESHOLD, first_layer: int = 1) -> None:
         """forward (training mode) + detections + both losses and their gradients wrt the
         head logits / score maps (yolo/yolo3_net_pos.py:59-60)."""
-        self._forward_layers(True)
+        self._forward_layers(True, first_layer)
         heads = [self.by_idx[75], self.by_idx[67], self.by_idx[59]]
         side = self.use_side_lane
         if side:
@@ -704,33 +747,34 @@ class YOLONet(object):
         return self.losses[7] + self.mask_loss[0] + self.reg_loss[0]
 
     # ---- recorded step: one C call (or one hipGraph launch) per iteration -------------
-    def build_program(self, det_thresh: float = cfg.OBJ_THRESHOLD, graph: bool = False) -> None:
+    def build_program(self, det_thresh: float = cfg.OBJ_THRESHOLD, graph: bool = False,
+                      pipeline_backbone: bool = False) -> None:
         """Record forward + losses + backward + Adam + re-pack into a command list
-        (csrc/runtime.hip).  With data parallelism the list is cut at the gradient-bucket
-        boundaries so the RCCL all-reduces are issued between segments."""
+        (csrc/runtime.hip).  With data parallelism the list is cut where a gradient bucket
+        becomes final so the RCCL all-reduces are issued between segments.
+
+        ``pipeline_backbone`` (stage 1 only): the locked backbone's forward pass does not depend
+        on anything the step updates, so the recorded step computes it for the NEXT batch's
+        images on a third lane while it runs heads/losses/backward/Adam for the current batch
+        (whose backbone pass ran during the previous step; outputs double-buffered).  Call
+        ``set_batch`` with labels of batch t and images of batch t+1, after ``prime_pipeline``.
+        """
         if not self.training:
             raise L.DisyoloError("build_program on a YOLONet built with training=False")
-        prog = L.CmdList()
-        marks = []
-        with prog:
-            self.compute_losses(det_thresh)
-            if self.n_decay:
-                L.l2_loss(self.arena, self.n_decay, self.l2, self.reg_loss, self.ws)
-            if self.dp is not None:
-                self.dp.begin_step()
-
-                def mark(l):
-                    # weight / bias gradients are produced on the side lane: the bucket's
-                    # all-reduce is ordered after that lane only (run_program), the main lane
-                    # is never stalled by the exchange
-                    bi = self.dp.completes_bucket(l)
-                    if bi is not None:
-                        marks.append((prog.size(), bi))
-                self.backward(mark)
-            else:
-                self.backward()
-            self._bwd_end = prog.size()
-            self.optimizer_step(1.0 / self.dp.world_size if self.dp is not None else 1.0)
+        if pipeline_backbone:
+            if graph:
+                raise L.DisyoloError("pipeline_backbone uses the list executor, not a hipGraph")
+            self._setup_pipeline()
+            self._progs = []
+            for q in (0, 1):
+                prog, marks, bwd_end = self._record_step(det_thresh, q)
+                self._progs.append((prog, marks, bwd_end))
+            self._use_parity(0)
+            self.ws.frozen = True
+            self.ws_aux.frozen = True
+            self._prog, self._prog_marks, self._bwd_end = self._progs[0]
+            return
+        prog, marks, self._bwd_end = self._record_step(det_thresh, None)
         self.ws.frozen = True
         self.ws_aux.frozen = True
         self._prog, self._prog_marks = prog, marks
@@ -755,7 +799,51 @@ class YOLONet(object):
                 prog.run()
             self._graph = g
 
+    def _record_step(self, det_thresh: float, parity):
+        """one recorded step; parity None = plain, 0/1 = pipelined (consumes backbone outputs of
+        that parity, produces the other)"""
+        prog = L.CmdList()
+        marks = []
+        with prog:
+            first = 1
+            if parity is not None:
+                self._use_parity(parity)
+                first = self._pipe_P + 1
+            self.compute_losses(det_thresh, first)
+            if parity is not None:
+                # the next batch's backbone: lowest-priority lane, started once the trunk's forward
+                # is done, so it fills the bubbles of the latency-bound backward chain
+                self._use_parity(1 - parity)
+                lane = int(os.environ.get("DISYOLO_PIPE_LANE", "2"))
+                L.lane_sync(0, lane)
+                L.set_lane(lane)
+                for l in self.layers[:self._pipe_P]:
+                    self._forward_layer(l, True)
+                L.set_lane(0)
+                self._use_parity(parity)
+            if self.n_decay:
+                L.l2_loss(self.arena, self.n_decay, self.l2, self.reg_loss, self.ws)
+            if self.dp is not None:
+                self.dp.begin_step()
+
+                def mark(l):
+                    # weight / bias gradients are produced on the side lane: the bucket's
+                    # all-reduce is ordered after that lane only (run_program), the main lane
+                    # is never stalled by the exchange
+                    bi = self.dp.completes_bucket(l)
+                    if bi is not None:
+                        marks.append((prog.size(), bi))
+                self.backward(mark)
+            else:
+                self.backward()
+            bwd_end = prog.size()
+            self.optimizer_step(1.0 / self.dp.world_size if self.dp is not None else 1.0)
+        return prog, marks, bwd_end
+
     def run_program(self) -> None:
+        if self._progs is not None:
+            self._prog, self._prog_marks, self._bwd_end = self._progs[self._parity]
+            self._parity ^= 1
         if self._graph is not None:
             self._graph.replay()
             return

@@ -238,7 +238,7 @@ void disyolo_cmdlist_destroy(void* list);
 int disyolo_cmdlist_begin(void* list);
 int disyolo_cmdlist_end(void);
 int disyolo_cmdlist_size(void* list);
-/* two lanes: 0 = the stream passed to cmdlist_run, 1 = a side stream owned by the list.
+/* three lanes: 0 = the stream passed to cmdlist_run, 1 and 2 = side streams owned by the list.
  * set_lane selects the lane of the launches recorded next; sync(from,to) makes lane `to` wait
  * for what lane `from` has recorded so far.  Both are no-ops outside a recording.  Every
  * cmdlist_run range forks the side lane after the caller's stream and joins it at the end. */

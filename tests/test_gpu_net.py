@@ -248,3 +248,31 @@ def test_recorded_step_is_bitwise_identical_to_eager(dev, graph):
     assert nets[0].step_count == nets[1].step_count == 3
     for name in nets[0].params:
         assert torch.equal(nets[0].params[name], nets[1].params[name]), name
+
+
+def test_pipelined_backbone_step_equals_plain_step(dev):
+    """Stage 1: the recorded step that computes the locked backbone of the NEXT images on a
+    third lane (double-buffered outputs) must reproduce the plain step bit for bit, with a
+    different batch every step."""
+    B, S = 2, 64
+    batches = [O.synthetic_batch(B, S, seed=40 + t) for t in range(4)]
+    plain = make_net(dev, True, 1, B=B, S=S, seed=6)
+    piped = make_net(dev, True, 1, B=B, S=S, seed=6)
+    piped.load_state_dict(plain.state_dict())
+    plain.build_program(det_thresh=0.1)
+    piped.build_program(det_thresh=0.1, pipeline_backbone=True)
+    piped._set_inputs(batches[0]["images"], batches[0]["clip_window"])
+    piped.prime_pipeline()
+    lp, lq = [], []
+    for t in range(3):
+        plain.set_batch(batches[t])
+        lp.append(float(plain.train_step(None).cpu()))
+        mixed = dict(batches[t])
+        mixed["images"] = batches[t + 1]["images"]        # labels of batch t, images of batch t+1
+        piped.set_batch(mixed)
+        lq.append(float(piped.train_step(None).cpu()))
+    torch.cuda.synchronize()
+    assert lp == lq
+    assert torch.equal(plain.arena, piped.arena) and torch.equal(plain.adam_v, piped.adam_v)
+    for name in plain.params:
+        assert torch.equal(plain.params[name], piped.params[name]), name
