@@ -196,8 +196,9 @@ def main():
         # the captured side lane): 1304 vs 1193 img/s on one MI355X
         mode = "program"
 
+    net.shuffle_seed = 1234 + rank   # tf.random_shuffle of the mask-loss RoIs: on the device, every step
+
     def step():
-        net.shuffle_rois(gen)      # tf.random_shuffle of the mask-loss RoIs, every step
         net.train_step(None, want_loss=False)
 
     # per-kernel durations for the roofline: HIP events around every conv launch over K eager

@@ -451,6 +451,7 @@ struct TileCfg {
 // variant are in dispatch()
 const TileCfg kTiles[] = {
     {1, 128, 128}, {2, 128, 64}, {3, 64, 128}, {4, 128, 32}, {5, 128, 16}, {6, 64, 64}, {7, 256, 64}, {8, 256, 128},
+    {9, 64, 128},
 };
 
 template <int BM, int BN, int WM, int WN, int BK, int ST>
@@ -493,6 +494,7 @@ int dispatch(int id, bool bk64, int variant, const ConvParams& p, hipStream_t s)
     DY_TILE(6, 64, 64, 2, 2, 3, 2, 4, 3)
     DY_TILE(7, 256, 64, 4, 1, 3, 2, 4, 3)
     DY_TILE(8, 256, 128, 4, 2, 2, 3, 3, 4)
+    DY_TILE(9, 64, 128, 2, 2, 6, 4, 6, 4)   // deep pipeline for layers with fewer blocks than CU slots
     default: disyolo_set_error("conv: unknown tile id %d", id); return DISYOLO_E_ARG;
   }
 }
@@ -551,8 +553,8 @@ extern "C" int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d) {
 
 // stages per (tile id, BK, variant): keep in sync with DY_TILE in dispatch()
 static int tile_stages(int id, bool bk64, int variant) {
-  static const int tab[9][4] = {{0, 0, 0, 0}, {2, 3, 3, 4}, {3, 2, 4, 3}, {2, 3, 4, 3}, {3, 2, 4, 3},
-                                {3, 2, 4, 3}, {3, 2, 4, 3}, {3, 2, 4, 3}, {2, 3, 3, 4}};
+  static const int tab[10][4] = {{0, 0, 0, 0}, {2, 3, 3, 4}, {3, 2, 4, 3}, {2, 3, 4, 3}, {3, 2, 4, 3},
+                                 {3, 2, 4, 3}, {3, 2, 4, 3}, {3, 2, 4, 3}, {2, 3, 3, 4}, {6, 4, 6, 4}};
   return tab[id][(bk64 ? 0 : 2) + (variant ? 1 : 0)];
 }
 

@@ -160,6 +160,33 @@ __global__ __launch_bounds__(320) void yolo_loss_final_kernel(const float* parti
   }
 }
 
+// ---- tf.random_shuffle of the proposal / GT-box order (yolo/yolo3_net_pos.py:781-782) ----
+// A uniformly random permutation of 0..n-1 per image: each thread draws one counter-based
+// 32-bit key (hash of seed, step, image, index), the rank of the key is its position.  The step
+// count is read from device memory, so a recorded step reshuffles on every replay.
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__global__ __launch_bounds__(64) void shuffle_perm_kernel(int* perm_a, int na, int* perm_b, int nb, unsigned seed,
+                                                          const int64_t* step) {
+  __shared__ unsigned keys[64];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const unsigned st = step ? (unsigned)*step : 0u;
+  for (int which = 0; which < 2; ++which) {
+    const int n = which ? nb : na;
+    int* out = (which ? perm_b : perm_a) + (size_t)b * n;
+    if (t < n) keys[t] = hash32(hash32(seed + 0x9e3779b9u * st) ^ hash32((unsigned)(b * 2 + which) * 0x85ebca6bu + t));
+    __syncthreads();
+    if (t < n) {
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += (keys[j] < keys[t]) || (keys[j] == keys[t] && j < t);
+      out[rank] = t;
+    }
+    __syncthreads();
+  }
+}
+
 // ---- mask-loss RoI selection (yolo/yolo3_net_pos.py:757-796, 842) ------------------
 constexpr int ROI_MAX = 16;
 constexpr int ROI_W = 12;  // gy0..3, gx0..3, gt_row, area, valid, pad
@@ -411,6 +438,16 @@ extern "C" int disyolo_yolo_loss(const float* const logits[3], const float* cons
   }
   hipLaunchKernelGGL(yolo_loss_final_kernel, dim3(1), dim3(320), 0, st, (const float*)workspace,
                      nblk[0] + nblk[1] + nblk[2], 1.f / (float)B, losses);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+extern "C" int disyolo_shuffle_perm(int32_t* perm_det, int n_det, int32_t* perm_gt, int n_gt, int B, uint32_t seed,
+                                    const int64_t* step_counter, void* stream) {
+  DY_REQUIRE(perm_det && perm_gt && B > 0 && n_det > 0 && n_det <= 64 && n_gt > 0 && n_gt <= 64, "shuffle_perm: bad args");
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_shuffle_perm(perm_det, n_det, perm_gt, n_gt, B, seed, step_counter, s); });
+  hipLaunchKernelGGL(shuffle_perm_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, perm_det, n_det, perm_gt, n_gt, seed,
+                     step_counter);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }

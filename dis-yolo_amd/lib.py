@@ -78,6 +78,7 @@ _SIGS = {
     "disyolo_yolo_loss_workspace": (C.c_size_t, [C.c_int] * 3),
     "disyolo_yolo_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_float] +
                           [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]),
+    "disyolo_shuffle_perm": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]),
     "disyolo_mask_rois": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 4 +
                           [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "disyolo_psroi_loss_workspace": (C.c_size_t, [C.c_int, C.c_int]),
@@ -273,7 +274,7 @@ def conv_flops(d: ConvDesc) -> float:
     return 2.0 * d.B * d.Ho * d.Wo * d.Cout * K / float(d.in_div * d.in_div)
 
 
-_WAVES = {1: (2, 2), 2: (2, 2), 3: (2, 2), 4: (4, 1), 5: (4, 1), 6: (2, 2), 7: (4, 1), 8: (4, 2)}
+_WAVES = {1: (2, 2), 2: (2, 2), 3: (2, 2), 4: (4, 1), 5: (4, 1), 6: (2, 2), 7: (4, 1), 8: (4, 2), 9: (2, 2)}
 
 
 def conv2d_tile(d: ConvDesc):
@@ -430,6 +431,11 @@ def yolo_loss(logits, labels, true_boxes, max_boxes, B, S, num_class, anchors_ho
     sc = (C.c_float * 4)(*[float(v) for v in scales])
     _check(load().disyolo_yolo_loss(lg, lb, _p(true_boxes), max_boxes, B, S, num_class, anc, ignore_thresh, sc, dl,
                                     _p(losses), _p(buf), buf.numel(), _stream()), "yolo_loss")
+
+
+def shuffle_perm(perm_det, perm_gt, B, seed, step_counter) -> None:
+    _check(load().disyolo_shuffle_perm(_p(perm_det), perm_det.shape[1], _p(perm_gt), perm_gt.shape[1], B, seed,
+                                       _p(step_counter), _stream()), "shuffle_perm")
 
 
 def mask_rois(detections, max_det, true_boxes, G, perm_det, perm_gt, B, map_size, n_det, n_gt, iou_thresh, rois,

@@ -612,10 +612,13 @@ class YOLONet(object):
             self.perm_gt.copy_(torch.as_tensor(batch["perm_gt"]).to(dev, torch.int32).reshape(self.perm_gt.shape))
 
     def shuffle_rois(self, generator: Optional[torch.Generator] = None) -> None:
-        """tf.random_shuffle of proposals / GT boxes (yolo/yolo3_net_pos.py:781-782)."""
+        """tf.random_shuffle of proposals / GT boxes (yolo/yolo3_net_pos.py:781-782), host-driven
+        (torch RNG).  A recorded step built with ``auto_shuffle`` does this on the device."""
         B = self.B
         self.perm_det.copy_(torch.rand(B, cfg.MAX_DETECTION, device=self.device, generator=generator).argsort(dim=1))
         self.perm_gt.copy_(torch.rand(B, cfg.MAX_BOX_PER_IMAGE, device=self.device, generator=generator).argsort(dim=1))
+
+    shuffle_seed = None   # set to an int: compute_losses reshuffles the RoI order on the device each step
 
     def compute_losses(self, det_thresh: float = cfg.OBJ_THRESHOLD, first_layer: int = 1) -> None:
         """forward (training mode) + detections + both losses and their gradients wrt the
@@ -628,6 +631,8 @@ class YOLONet(object):
             # side lane, while the main lane does the YOLO loss and the heads' backward
             L.lane_sync(0, 1)
             L.set_lane(1)
+        if self.shuffle_seed is not None:
+            L.shuffle_perm(self.perm_det, self.perm_gt, self.B, int(self.shuffle_seed) & 0xffffffff, self.step_dev)
         self._detect(det_thresh)
         Sm = self.S // 2
         L.mask_rois(self.detections, cfg.MAX_DETECTION, self.true_boxes, cfg.MAX_BOX_PER_IMAGE, self.perm_det,

@@ -194,6 +194,11 @@ int disyolo_mask_rois(const float* detections, int max_det, const float* true_bo
                       const int32_t* perm_det, const int32_t* perm_gt, int B, int map_size,
                       int n_det, int n_gt, float iou_thresh, int32_t* rois, int32_t* roi_count,
                       void* stream);
+/* tf.random_shuffle replacement (:781-782): uniformly random permutations perm_det int32
+ * [B,n_det], perm_gt int32 [B,n_gt] from a counter-based hash of (seed, *step_counter, image);
+ * step_counter (device int64, may be NULL) makes every replay of a recorded step reshuffle */
+int disyolo_shuffle_perm(int32_t* perm_det, int n_det, int32_t* perm_gt, int n_gt, int B, uint32_t seed,
+                         const int64_t* step_counter, void* stream);
 /* masked BCE over assembled logits + gradient wrt the score maps (:799-858).
  * score f32 [B,Sm,Sm,k*k]; true_masks uint8 [B,G,2Sm,2Sm]; dscore bf16 [B,Sm,Sm,32] (padded);
  * loss f32[1] = mask_scale * mean_b(mean_r(sum BCE / area)). */

@@ -276,3 +276,24 @@ def test_pipelined_backbone_step_equals_plain_step(dev):
     assert torch.equal(plain.arena, piped.arena) and torch.equal(plain.adam_v, piped.adam_v)
     for name in plain.params:
         assert torch.equal(plain.params[name], piped.params[name]), name
+
+
+def test_device_shuffle_produces_fresh_uniform_permutations(dev):
+    B = 64
+    pd = torch.zeros(B, 30, dtype=torch.int32, device=dev)
+    pg = torch.zeros(B, 20, dtype=torch.int32, device=dev)
+    step = torch.zeros(1, dtype=torch.int64, device=dev)
+    seen = []
+    first_pos = np.zeros(30)
+    for s in range(40):
+        step.fill_(s)
+        L.shuffle_perm(pd, pg, B, 7, step)
+        torch.cuda.synchronize()
+        a, g = pd.cpu().numpy(), pg.cpu().numpy()
+        assert (np.sort(a, axis=1) == np.arange(30)).all() and (np.sort(g, axis=1) == np.arange(20)).all()
+        seen.append(a.copy())
+        first_pos += np.bincount(a[:, 0], minlength=30)
+    assert not np.array_equal(seen[0], seen[1])                    # reshuffled every step
+    assert len({tuple(r) for r in seen[0]}) == B                   # and per image
+    # 2560 draws of the first element: every value appears, none dominates
+    assert first_pos.min() > 40 and first_pos.max() < 140
