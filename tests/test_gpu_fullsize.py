@@ -145,3 +145,58 @@ def test_inference_masks_are_half_outside_boxes_at_full_size(dev):
     det2, _, masks2, _ = net.infer()
     torch.cuda.synchronize()
     assert np.array_equal(det2.cpu().numpy(), det) and np.array_equal(masks2.cpu().numpy(), masks)
+
+
+def test_config0_single_image_576_forward_matches_oracle(dev):
+    """BASELINE.json configs[0]: 1x576x576, 3 classes, inference forward (the
+    calculate_test_map.py path) -- the CPU oracle at full size against the HIP path:
+    head logits, score maps, filtered detections and assembled masks."""
+    import disyolo_oracle as O
+    net = YOLONet(training=False, device=dev, image_size=S, batch_size=1, stage=1, seed=0)
+    with torch.no_grad():
+        for i in (59, 67, 75, 82):
+            net.params["yolo/convolutional%d/weights" % i].mul_(4.0)
+            net.params["yolo/convolutional%d/biases" % i].normal_(0, 0.3)
+    net.refresh_weights()
+    b = synthetic_batch(1, S, seed=123)
+    window = np.array([[0.05, 0.0, 0.95, 1.0]], np.float32)            # letterbox-style clip window
+    det_box, det_mask = net.evaluation(b["images"], window, [0.2])
+    torch.cuda.synchronize()
+    p = {k: v.detach().cpu() for k, v in net.params.items()}
+    img = torch.from_numpy(b["images"])
+    yq, mq = O.build_network(p, img, False, O.default_lock(1), quant=O.bf16_ste)
+    yf, mf = O.build_network(p, img, False, O.default_lock(1))
+    preds = [net.by_idx[i].act.cpu().view(1, net.by_idx[i].Ho, net.by_idx[i].Wo, 3, 8) for i in (75, 67, 59)]
+    for got, wq, wf in list(zip(preds, yq, yf)) + [(net.by_idx[82].act.cpu(), mq, mf)]:
+        e_q = float((got.double() - wq.double()).norm() / wq.double().norm())
+        e_f = float((got.double() - wf.double()).norm() / wf.double().norm())
+        assert e_q < 2e-2 and e_f < 8e-2, (e_q, e_f)
+    # detection filter + mask assembly: exact on the kernels' own logits / score maps
+    pred = O.interpret_output(preds)
+    want_det = O.filter_detections(pred[2], pred[3], pred[5], window, 0.2)
+    np.testing.assert_allclose(net.detections.cpu().numpy(), want_det, rtol=1e-5, atol=1e-6)
+    wb, wm = O.val_test(net.detections.cpu().numpy(), net.by_idx[82].act.cpu())
+    assert len(wb[0]) > 0
+    np.testing.assert_array_equal(det_box[0], wb[0])
+    np.testing.assert_allclose(det_mask[0], wm[0], rtol=1e-5, atol=1e-6)
+    assert (wb[0][:, 0] >= 0.05 - 1e-6).all() and (wb[0][:, 2] <= 0.95 + 1e-6).all()
+
+
+def test_empty_and_saturated_detection_edge_cases(dev):
+    """no candidate above the threshold -> zero rows, count 0, evaluation returns the scalar
+    0.0 mask (yolo/yolo3_net_pos.py:933); more than 30 survivors -> exactly 30, best first."""
+    net = YOLONet(training=False, device=dev, image_size=192, batch_size=2, stage=1, seed=0)
+    b = synthetic_batch(2, 192, seed=1)
+    box, mask = net.evaluation(b["images"], b["clip_window"], [0.999])
+    assert net.det_count.cpu().tolist() == [0, 0] and float(net.detections.abs().sum()) == 0.0
+    assert all(bx.shape == (0, 6) for bx in box) and all(np.ndim(m) == 0 and m == 0.0 for m in mask)
+    # flood: huge positive confidence everywhere -> every candidate passes; NMS still caps at 30
+    with torch.no_grad():
+        for i in (59, 67, 75):
+            net.params["yolo/convolutional%d/biases" % i].view(3, 8)[:, 4] = 8.0
+            net.params["yolo/convolutional%d/biases" % i].view(3, 8)[:, 2:4] = -2.5   # small boxes: little overlap
+    net.refresh_weights()
+    box, mask = net.evaluation(b["images"], b["clip_window"], [0.01])
+    assert net.det_count.cpu().tolist() == [30, 30]
+    d = net.detections.cpu().numpy()
+    assert (np.diff(d[:, :, 5], axis=1) <= 0).all() and (d[:, :, 5] > 0.01).all()
