@@ -91,7 +91,9 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int ST>
+// KS = filter size (1 or 3) is a compile-time parameter: the 1x1 instance drops the tap cursor
+// and the per-tap offset refresh altogether (and shows up as its own row in a profile).
+template <int BM, int BN, int WM, int WN, int BK, int ST, int KS>
 __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void conv_igemm_kernel(ConvParams p) {
   constexpr int NW = WM * WN;
   constexpr int T = NW * 64;
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void
 
   auto issue_tile = [&](int stage) {
     const unsigned sbase = lds0 + stage * STB + wave * 1024;
-    if (ci0 == 0) {  // new filter tap (wave-uniform): refresh the per-lane pixel offsets
+    if (ci0 == 0 && (KS == 3 || k0 == 0)) {  // new filter tap (wave-uniform): refresh the per-lane pixel offsets
       if (p.dshift == 0) {
         const unsigned tapoff = (unsigned)((kh * p.W + kw) * p.C0) * 2u;
 #pragma unroll
@@ -223,9 +225,9 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void
     // advance the K cursor by one BK-wide slice
     k0 += BK;
     ci0 += BK;
-    if (ci0 >= p.Cin) {
+    if (KS == 3 && ci0 >= p.Cin) {
       ci0 = 0;
-      if (++kw == p.ks) {
+      if (++kw == 3) {
         kw = 0;
         ++kh;
       }
@@ -454,8 +456,8 @@ const TileCfg kTiles[] = {
     {9, 64, 128},
 };
 
-template <int BM, int BN, int WM, int WN, int BK, int ST>
-int launch(const ConvParams& p, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int BK, int ST, int KS>
+int launch_ks(const ConvParams& p, hipStream_t s) {
   ConvParams q = p;
   q.tilesM = ceil_div(p.M, BM);
   q.tilesN = ceil_div(p.Cout, BN);
@@ -468,13 +470,17 @@ int launch(const ConvParams& p, hipStream_t s) {
   if (red > lds) lds = red;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, ST>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, ST, KS>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, ST>), dim3(grid), dim3(NW * 64), lds, s, q);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, ST, KS>), dim3(grid), dim3(NW * 64), lds, s, q);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
+}
+template <int BM, int BN, int WM, int WN, int BK, int ST>
+int launch(const ConvParams& p, hipStream_t s) {
+  return p.ks == 3 ? launch_ks<BM, BN, WM, WN, BK, ST, 3>(p, s) : launch_ks<BM, BN, WM, WN, BK, ST, 1>(p, s);
 }
 
 // BK = 64 needs every source's channel count to be a multiple of 64 (a K slice never

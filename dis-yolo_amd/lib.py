@@ -290,7 +290,7 @@ def conv2d_fwd(d: ConvDesc) -> None:
     if TIMER is not None:
         if not hasattr(d, "_tname"):
             tid, bm, bn, bk, st = conv2d_tile(d)
-            d._tname = "conv_igemm_kernel<%d,%d,%d,%d,%d,%d>" % ((bm, bn) + _WAVES[tid] + (bk, st))
+            d._tname = "conv_igemm_kernel<%d,%d,%d,%d,%d,%d,%d>" % ((bm, bn) + _WAVES[tid] + (bk, st, d.ksize))
         TIMER.run(d._tname, conv_flops(d), lambda: _check(load().disyolo_conv2d_fwd(C.byref(d), _stream()),
                                                            "conv2d_fwd"))
         return
