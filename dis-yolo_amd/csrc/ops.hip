@@ -17,51 +17,74 @@ extern "C" int disyolo_version(void) { return 100; }
 namespace {
 
 // ---- conv 1: Cin = 3, k = 3, s = 1, SAME (yolo/yolo3_net_pos.py:159) ---------------
-// Exact f32 FMA (27 taps) per output; 1 thread = 1 pixel x 8 output channels.
+// Exact f32 FMA (27 taps) per output; 1 thread = 1 pixel x all COUT channels: the 27 input
+// values are loaded once into registers, the weights are wave-uniform scalar loads (SGPR operands).
 template <int COUT>
-__global__ __launch_bounds__(256) void conv_first_kernel(const float* img, const float* w, const float* scale,
-                                                         const float* shift, bf16* y, int B, int H, int W,
-                                                         float alpha) {
-  __shared__ float sw[27 * COUT];
-  for (int i = threadIdx.x; i < 27 * COUT; i += 256) sw[i] = w[i];
-  __syncthreads();
-  constexpr int G = COUT / 8;
-  const int64_t total = (int64_t)B * H * W * G;
+__global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ img, const float* __restrict__ sw,
+                                                         const float* __restrict__ ssc,
+                                                         const float* __restrict__ ssh, bf16* __restrict__ y, int B,
+                                                         int H, int W, float alpha) {
+  // each wave stages its 64 pixels x COUT bf16 in LDS so the global stores are contiguous 1 KiB rows
+  __shared__ uint4 stage[4][64 * (COUT / 8)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t total = (int64_t)B * H * W;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int cg = (int)(t % G);
-    int64_t m = t / G;
-    const int x = (int)(m % W);
-    const int64_t m2 = m / W;
-    const int yy = (int)(m2 % H);
-    const int b = (int)(m2 / H);
-    float acc[8];
+  const int64_t rounds = (total + stride - 1) / stride;
+  for (int64_t r = 0; r < rounds; ++r) {
+    const int64_t m = r * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t wave_m0 = m - lane;
+    if (m < total) {
+      const int x = (int)(m % W);
+      const int64_t m2 = m / W;
+      const int yy = (int)(m2 % H);
+      const int b = (int)(m2 / H);
+      float in[27];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+      for (int kh = 0; kh < 3; ++kh) {
+        const int iy = yy + kh - 1;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int iy = yy + kh - 1;
-      if ((unsigned)iy >= (unsigned)H) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+          const int ix = x + kw - 1;
+          const bool ok = ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+          const float* px = img + ((size_t)(b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * 3;
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int ix = x + kw - 1;
-        if ((unsigned)ix >= (unsigned)W) continue;
-        const float* px = img + ((size_t)(b * H + iy) * W + ix) * 3;
+          for (int ci = 0; ci < 3; ++ci) in[(kh * 3 + kw) * 3 + ci] = ok ? px[ci] : 0.f;
+        }
+      }
 #pragma unroll
-        for (int ci = 0; ci < 3; ++ci) {
-          const float v = px[ci];
-          const float* wr = sw + ((kh * 3 + kw) * 3 + ci) * COUT + cg * 8;
+      for (int cg = 0; cg < COUT / 8; ++cg) {
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+          const float v = in[t];
+          const float* wr = sw + t * COUT + cg * 8;
 #pragma unroll
           for (int k = 0; k < 8; ++k) acc[k] = fmaf(v, wr[k], acc[k]);
         }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = leaky(acc[k] * ssc[cg * 8 + k] + ssh[cg * 8 + k], alpha);
+        // chunk index XOR-swizzled by pixel so the 64 B-strided writes spread over the banks
+        stage[wave][lane * (COUT / 8) + (cg ^ ((lane >> 1) & (COUT / 8 - 1)))] = pack8(acc);
       }
     }
+    // same wave wrote and reads: no block barrier needed, only LDS ordering
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (wave_m0 < total) {
+      uint4* dst = reinterpret_cast<uint4*>(y + (size_t)wave_m0 * COUT);
+      const int64_t lim = (total - wave_m0) * (COUT / 8);  // valid 16 B chunks of this wave's row block
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int c = cg * 8 + k;
-      acc[k] = leaky(acc[k] * scale[c] + shift[c], alpha);
+      for (int i = 0; i < COUT / 8; ++i) {
+        const int c = i * 64 + lane;  // chunk in the wave's contiguous output
+        const int p = c / (COUT / 8), cg = c % (COUT / 8);
+        if (c < lim) dst[c] = stage[wave][p * (COUT / 8) + (cg ^ ((p >> 1) & (COUT / 8 - 1)))];
+      }
     }
-    *reinterpret_cast<uint4*>(y + (size_t)m * COUT + cg * 8) = pack8(acc);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -232,7 +255,7 @@ extern "C" int disyolo_conv_first_fwd(const float* images, const float* w_hwio, 
   DY_REQUIRE(images && w_hwio && scale && shift && y_bf16 && B > 0 && H > 0 && W > 0, "conv_first: bad args");
   DY_REQUIRE(Cout == 32, "conv_first: Cout must be 32 (got %d)", Cout);
   DY_RECORD_OR_RUN([=](void* s) { return disyolo_conv_first_fwd(images, w_hwio, scale, shift, y_bf16, B, H, W, Cout, alpha, s); });
-  const int64_t total = (int64_t)B * H * W * (Cout / 8);
+  const int64_t total = (int64_t)B * H * W;
   int grid = ceil_div(total, 256);
   if (grid > 256 * 16) grid = 256 * 16;
   hipLaunchKernelGGL(conv_first_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, images, w_hwio, scale,

@@ -43,7 +43,7 @@ def plan_buckets(layer_spans: List[Tuple[int, int, int]], bucket_elems: int) -> 
 
 
 class GradientAllReduce:
-    def __init__(self, net, process_group=None, bucket_mb: float = 24.0):
+    def __init__(self, net, process_group=None, bucket_mb: float = 12.0):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.net = net
@@ -119,6 +119,6 @@ def broadcast_parameters(net, src: int = 0, process_group=None) -> None:
     net.refresh_weights()
 
 
-def enable_data_parallel(net, process_group=None, bucket_mb: float = 24.0) -> GradientAllReduce:
+def enable_data_parallel(net, process_group=None, bucket_mb: float = 12.0) -> GradientAllReduce:
     net.dp = GradientAllReduce(net, process_group, bucket_mb)
     return net.dp
