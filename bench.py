@@ -155,6 +155,9 @@ def main():
                     help="cross-step software pipeline of the locked backbone (stage 1): each step computes the "
                          "backbone forward of the NEXT batch on a third lane while it runs heads/losses/backward/Adam "
                          "of the current one (bit-identical results, but measured slower: auto = off)")
+    ap.add_argument("--autotune", default="on", choices=("on", "off"),
+                    help="time the conv tile candidates inside the layer sequence before recording the step "
+                         "(setup, outside the timed region)")
     ap.add_argument("--force-dp", action="store_true",
                     help="initialise RCCL and run the bucketed gradient all-reduce path even with one rank (self-test)")
     ap.add_argument("--mode", default="auto", choices=("auto", "graph", "program", "eager"),
@@ -189,6 +192,12 @@ def main():
     net.set_batch(batch)           # inputs resident in HBM from here on
     torch.manual_seed(1234 + rank)
     gen = None                     # default CUDA generator
+    if args.autotune == "on":
+        t_tune = time.perf_counter()
+        picks = net.autotune()
+        if rank == 0:
+            print("autotune %.1f s: %d of %d conv shapes moved off the launcher heuristic"
+                  % (time.perf_counter() - t_tune, sum(1 for v in picks.values() if v), len(picks)), file=sys.stderr)
 
     mode = args.mode
     if mode == "auto":
@@ -249,7 +258,7 @@ def main():
         value = world * B * args.steps / dt
         train_gflop = TRAIN_GFLOP_PER_IMG_576[args.stage] * (S / 576.0) ** 2
         out = {
-            "metric": "train images/sec @576x576 bf16",
+            "metric": "train images/sec @%dx%d bf16" % (S, S),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -257,7 +266,9 @@ def main():
                        "images_per_gpu": B, "global_batch": B * world, "image_size": S,
                        "stage": "1: conv1-52 locked (shipped reference source)" if args.stage == 1 else
                                 "2: all 82 layers trainable",
-                       "parallelism": "dp%d" % world, "rccl_buckets": (len(net.dp.buckets) + 1) if net.dp else 0, "optimizer": "adam(tf-form) lr=1e-4", "step_driver": mode, "backbone_pipeline": bool(args.stage == 1 and mode == "program" and args.pipeline == "on"),
+                       "parallelism": "dp%d" % world, "rccl_buckets": (len(net.dp.buckets) + 1) if net.dp else 0, "optimizer": "adam(tf-form) lr=1e-4", "step_driver": mode,
+                       "conv_tiles": "autotuned in-sequence at setup" if args.autotune == "on" else "launcher heuristic",
+                       "backbone_pipeline": bool(args.stage == 1 and mode == "program" and args.pipeline == "on"),
                        "final_total_loss": round(loss, 4)},
             "model_flops": {"train_gflop_per_image": round(train_gflop, 1),
                             "achieved_tflops_per_gpu": round(train_gflop * value / world / 1e3, 1),

@@ -93,10 +93,16 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // KS = filter size (1 or 3) is a compile-time parameter: the 1x1 instance drops the tap cursor
 // and the per-tap offset refresh altogether (and shows up as its own row in a profile).
-template <int BM, int BN, int WM, int WN, int BK, int ST, int KS>
-__global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void conv_igemm_kernel(ConvParams p) {
-  constexpr int NW = WM * WN;
-  constexpr int T = NW * 64;
+//
+// KG > 1 = intra-block split-K: the block has KG groups of WM*WN waves; group g multiplies the
+// K slices g, g+KG, ... of the SAME output tile from its own LDS ring, and the groups' f32
+// accumulators are summed through LDS (fixed order) before group 0 runs the epilogue.  It
+// doubles the waves per CU for the layers whose M*N gives barely one block per CU (18^2, 36^2),
+// where one wave per SIMD cannot overlap its DMA issue with its MFMAs.
+template <int BM, int BN, int WM, int WN, int BK, int ST, int KS, int KG = 1>
+__global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1) void conv_igemm_kernel(ConvParams p) {
+  constexpr int NW = WM * WN;         // waves per K group
+  constexpr int T = NW * 64;          // threads per K group
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 16, NI = WTN / 16;
   constexpr int ROWB = BK * 2;        // bytes per LDS row
@@ -116,8 +122,11 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = KG == 1 ? 0 : wave_all / NW;     // K group of this wave
+  const int wave = KG == 1 ? wave_all : wave_all % NW;
   const int wm = wave / WN, wn = wave % WN;
+  const int nkg = p.nk / KG;                      // K slices per group (the launcher guarantees divisibility)
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a
   // contiguous run of tiles, n-tile fastest, so the blocks that re-read one pixel panel
@@ -183,10 +192,26 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void
   }
 
   int kh = 0, kw = 0, ci0 = 0, k0 = 0;  // wave-uniform K cursor of the next tile to fetch
+  bool newtap = true;
+  auto advance = [&]() {  // move the K cursor by one BK-wide slice
+    k0 += BK;
+    ci0 += BK;
+    if (KS == 3 && ci0 >= p.Cin) {
+      ci0 = 0;
+      newtap = true;
+      if (++kw == 3) {
+        kw = 0;
+        ++kh;
+      }
+    }
+  };
+  if (KG > 1)
+    for (int g = 0; g < kg; ++g) advance();
 
   auto issue_tile = [&](int stage) {
-    const unsigned sbase = lds0 + stage * STB + wave * 1024;
-    if (ci0 == 0 && (KS == 3 || k0 == 0)) {  // new filter tap (wave-uniform): refresh the per-lane pixel offsets
+    const unsigned sbase = lds0 + (kg * ST + stage) * STB + wave * 1024;
+    if (newtap) {  // new filter tap (wave-uniform): refresh the per-lane pixel offsets
+      newtap = false;
       if (p.dshift == 0) {
         const unsigned tapoff = (unsigned)((kh * p.W + kw) * p.C0) * 2u;
 #pragma unroll
@@ -207,10 +232,18 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void
         }
       }
     }
+#ifdef DY_PROBE
+    // traffic probes: 0x20000 = only tap (0,0) fetches pixels, 0x40000 = only every other
+    // slice fetches weights (the skipped DMAs still issue, out of range: zeros, no traffic)
+    const bool skipA = (p.flags & 0x20000) && (kh | kw);
+    const bool skipB = (p.flags & 0x40000) && ((k0 / BK) & 1);
+#else
+    constexpr bool skipA = false, skipB = false;
+#endif
     if (ci0 < p.C0) {
       const unsigned cs2 = ci0 * 2;
       [&]<int... J>(std::integer_sequence<int, J...>) {
-        (dma16<J * SLAB>(a_base[J], srd0, cs2, sbase), ...);
+        (dma16<J * SLAB>(skipA ? OOB : a_base[J], srd0, cs2, sbase), ...);
       }(std::make_integer_sequence<int, AI>{});
     } else {
       const unsigned cs2 = (ci0 - p.C0) * 2;
@@ -220,18 +253,10 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void
     }
     const unsigned k2 = k0 * 2;
     [&]<int... J>(std::integer_sequence<int, J...>) {
-      (dma16<A_BYTES + J * SLAB>(b_base[J], srdw, k2, sbase), ...);
+      (dma16<A_BYTES + J * SLAB>(skipB ? OOB : b_base[J], srdw, k2, sbase), ...);
     }(std::make_integer_sequence<int, BI>{});
-    // advance the K cursor by one BK-wide slice
-    k0 += BK;
-    ci0 += BK;
-    if (KS == 3 && ci0 >= p.Cin) {
-      ci0 = 0;
-      if (++kw == 3) {
-        kw = 0;
-        ++kh;
-      }
-    }
+#pragma unroll
+    for (int g = 0; g < KG; ++g) advance();
   };
 
   f32x4 acc[MI][NI];
@@ -246,14 +271,14 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void
   //      kt+PRE, then multiply tile kt.
 #pragma unroll
   for (int s = 0; s < PRE; ++s)
-    if (s < p.nk) issue_tile(s);
+    if (s < nkg) issue_tile(s);
 
   const int frow = lane & 15, fchunk = lane >> 4;
 #ifdef DY_PROBE
   bf16x8 pxf[2][MI], pwf[2][NI];
 #endif
-  for (int kt = 0; kt < p.nk; ++kt) {
-    if (PRE >= 1 && kt + PRE - 1 < p.nk)
+  for (int kt = 0; kt < nkg; ++kt) {
+    if (PRE >= 1 && kt + PRE - 1 < nkg)
       wait_vmcnt<LPT*(PRE >= 1 ? PRE - 1 : 0)>();
     else
       wait_vmcnt<0>();
@@ -263,9 +288,9 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void
     // ablation build (tools/bin/libdisyolo_probe.so): 0x4000 = no DMA in the loop,
     // 0x8000 = fragments read once, 0x10000 = no MFMA
     if (PRE >= 1) {
-      if (kt + PRE < p.nk && !(p.flags & 0x4000)) issue_tile((kt + PRE) % ST);
+      if (kt + PRE < nkg && !(p.flags & 0x4000)) issue_tile((kt + PRE) % ST);
     }
-    const char* sA = smem + (kt % ST) * STB;
+    const char* sA = smem + (kg * ST + kt % ST) * STB;
     const char* sB = sA + A_BYTES;
     static_assert(BK / 32 <= 2, "");
     bf16x8 xf[2][MI], wf[2][NI];
@@ -310,9 +335,9 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void
     }
 #else
     if (PRE >= 1) {
-      if (kt + PRE < p.nk) issue_tile((kt + PRE) % ST);
+      if (kt + PRE < nkg) issue_tile((kt + PRE) % ST);
     }
-    const char* sA = smem + (kt % ST) * STB;
+    const char* sA = smem + (kg * ST + kt % ST) * STB;
     const char* sB = sA + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
@@ -336,10 +361,40 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void
 #endif
     if (PRE == 0) {  // single stage: refill only after everyone has consumed the tile
       __builtin_amdgcn_s_barrier();
-      if (kt + 1 < p.nk) issue_tile(0);
+      if (kt + 1 < nkg) issue_tile(0);
     }
   }
   __syncthreads();  // all fragment reads done before the LDS is reused by the epilogue
+
+  if (KG > 1) {
+    // sum the groups' accumulators in group order through LDS ([KG-1][MI*NI][T] float4)
+    float4* xg = reinterpret_cast<float4*>(smem);
+    if (kg > 0) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          xg[((kg - 1) * MI * NI + i * NI + j) * T + wave * 64 + lane] =
+              make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int g = 1; g < KG; ++g)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const float4 v = xg[((g - 1) * MI * NI + i * NI + j) * T + wave * 64 + lane];
+            acc[i][j][0] += v.x;
+            acc[i][j][1] += v.y;
+            acc[i][j][2] += v.z;
+            acc[i][j][3] += v.w;
+          }
+    }
+    __syncthreads();
+  }
+  const bool ep = (KG == 1) || (kg == 0);   // only group 0 holds the full sums
 
   // ---- epilogue.  acc[i][j][r]: pixel m0 + wm*WTM + i*16 + (lane&15),
   //      channel n0 + wn*WTN + j*16 + 4*(lane>>4) + r ----
@@ -366,7 +421,7 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void
           s += __shfl_xor(s, o, 64);
           s2 += __shfl_xor(s2, o, 64);
         }
-        if (px == 0) {
+        if (px == 0 && ep) {
           const int nl = wn * WTN + j * 16 + cq * 4 + r;
           red[(wm * BN + nl) * 2 + 0] = s;
           red[(wm * BN + nl) * 2 + 1] = s2;
@@ -374,7 +429,7 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void
       }
     }
     __syncthreads();
-    for (int nl = tid; nl < BN; nl += T) {
+    for (int nl = tid; nl < BN; nl += T * KG) {
       const int n = n0 + nl;
       if (n < p.Cout) {
         float s = 0.f, s2 = 0.f;
@@ -389,6 +444,7 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void
     }
   }
 
+  if (!ep) return;
   const bool vec_ok = (p.Cout & 3) == 0;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
@@ -453,10 +509,10 @@ struct TileCfg {
 // variant are in dispatch()
 const TileCfg kTiles[] = {
     {1, 128, 128}, {2, 128, 64}, {3, 64, 128}, {4, 128, 32}, {5, 128, 16}, {6, 64, 64}, {7, 256, 64}, {8, 256, 128},
-    {9, 64, 128},
+    {9, 64, 128}, {10, 96, 128}, {11, 96, 128}, {12, 192, 128}, {13, 64, 128}, {14, 96, 128}, {15, 192, 128},
 };
 
-template <int BM, int BN, int WM, int WN, int BK, int ST, int KS>
+template <int BM, int BN, int WM, int WN, int BK, int ST, int KS, int KG = 1>
 int launch_ks(const ConvParams& p, hipStream_t s) {
   ConvParams q = p;
   q.tilesM = ceil_div(p.M, BM);
@@ -465,22 +521,24 @@ int launch_ks(const ConvParams& p, hipStream_t s) {
   const int grid = q.tilesM * q.tilesN;
   constexpr int NW = WM * WN, SLAB = 1024 * NW, ROWB = BK * 2;
   constexpr int A_BYTES = (BM * ROWB + SLAB - 1) / SLAB * SLAB, B_BYTES = (BN * ROWB + SLAB - 1) / SLAB * SLAB;
-  size_t lds = (size_t)ST * (A_BYTES + B_BYTES);
+  size_t lds = (size_t)KG * ST * (A_BYTES + B_BYTES);
   const size_t red = (size_t)WM * BN * 2 * sizeof(float);
   if (red > lds) lds = red;
+  const size_t xg = (size_t)(KG - 1) * BM * BN * sizeof(float);
+  if (xg > lds) lds = xg;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, ST, KS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, ST, KS, KG>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, ST, KS>), dim3(grid), dim3(NW * 64), lds, s, q);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, ST, KS, KG>), dim3(grid), dim3(NW * 64 * KG), lds, s, q);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }
-template <int BM, int BN, int WM, int WN, int BK, int ST>
+template <int BM, int BN, int WM, int WN, int BK, int ST, int KG = 1>
 int launch(const ConvParams& p, hipStream_t s) {
-  return p.ks == 3 ? launch_ks<BM, BN, WM, WN, BK, ST, 3>(p, s) : launch_ks<BM, BN, WM, WN, BK, ST, 1>(p, s);
+  return p.ks == 3 ? launch_ks<BM, BN, WM, WN, BK, ST, 3, KG>(p, s) : launch_ks<BM, BN, WM, WN, BK, ST, 1, KG>(p, s);
 }
 
 // BK = 64 needs every source's channel count to be a multiple of 64 (a K slice never
@@ -490,8 +548,21 @@ int launch(const ConvParams& p, hipStream_t s) {
   case ID:                                                                                          \
     if (bk64) return variant ? launch<BM, BN, WM, WN, 64, S64B>(p, s) : launch<BM, BN, WM, WN, 64, S64A>(p, s); \
     return variant ? launch<BM, BN, WM, WN, 32, S32B>(p, s) : launch<BM, BN, WM, WN, 32, S32A>(p, s);
+// split-K tiles (two K groups per block) need BK = 64 and an even number of K slices;
+// otherwise the plain tile of the same shape runs
+int resolve_tile(int id, bool bk64, int K) {
+  if (id >= 13 && id <= 15) {
+    const bool ok = bk64 && (K / 64) % 2 == 0 && K >= 512;
+    if (!ok) id = id == 13 ? 3 : id == 14 ? 10 : 12;
+  }
+  return id;
+}
 int dispatch(int id, bool bk64, int variant, const ConvParams& p, hipStream_t s) {
+  id = resolve_tile(id, bk64, p.K);
   switch (id) {
+    case 13: return variant ? launch<64, 128, 2, 2, 64, 3, 2>(p, s) : launch<64, 128, 2, 2, 64, 2, 2>(p, s);
+    case 14: return launch<96, 128, 2, 2, 64, 2, 2>(p, s);   // 3 stages x 2 groups would need 168 KiB
+    case 15: return launch<192, 128, 4, 2, 64, 2, 2>(p, s);
     DY_TILE(1, 128, 128, 2, 2, 2, 3, 3, 4)
     DY_TILE(2, 128, 64, 2, 2, 3, 2, 4, 3)
     DY_TILE(3, 64, 128, 2, 2, 2, 3, 4, 3)
@@ -501,25 +572,36 @@ int dispatch(int id, bool bk64, int variant, const ConvParams& p, hipStream_t s)
     DY_TILE(7, 256, 64, 4, 1, 3, 2, 4, 3)
     DY_TILE(8, 256, 128, 4, 2, 2, 3, 3, 4)
     DY_TILE(9, 64, 128, 2, 2, 6, 4, 6, 4)   // deep pipeline for layers with fewer blocks than CU slots
+    DY_TILE(10, 96, 128, 2, 2, 2, 3, 4, 3)  // 48x64 wave tiles: fewer bytes staged per FLOP than 64x128
+    DY_TILE(11, 96, 128, 2, 2, 4, 5, 6, 4)  // the same, deep pipeline (one block per CU)
+    DY_TILE(12, 192, 128, 4, 2, 2, 3, 3, 4) // 8 waves of 48x64
     default: disyolo_set_error("conv: unknown tile id %d", id); return DISYOLO_E_ARG;
   }
 }
 
-// Launcher heuristic, from the per-layer sweep of tools/bench_conv.py on MI355X (B = 8, 576^2;
-// profiles/r01_conv_tile_sweep.txt).  Occupancy beats pipeline depth on these shapes: the
-// 64x128 tile (94 registers, 48 KiB LDS at BK=64 x 2 stages -> 3 blocks per CU) is within a few
-// percent of the best everywhere; the 8-wave 256x128 tile at BK=32 wins where M is huge.
-// Returns id | flags: bit 8 = force BK 32, bit 9 = alternative pipeline depth.
+// Launcher heuristic = the consensus of the in-sequence autotuner (YOLONet.autotune, which
+// times every candidate where it runs: inside the step, operands as cold as they really are)
+// over the layer shapes of the B = 8, 576^2 network; profiles/r01g_autotune.txt.  Stand-alone
+// timing loops (tools/bench_conv.py) keep a layer's operands hot in L2 and rank the tiles
+// differently -- rules taken from them measured 1-3 % SLOWER end to end.  What the picks say:
+// huge-M layers want the 8-wave 192x128 tile (48x64 wave tiles: fewest bytes staged per
+// FLOP) as long as it still yields > 1 block per CU; everything else wants MANY small blocks
+// (64x64 / 128x64) -- occupancy and short epilogues beat staging efficiency when a layer is
+// only ~10 us of MFMA work.  Returns id | flags: bit 8 = force BK 32, bit 9 = alternative
+// pipeline depth.  A caller that tunes for its own shapes passes the result in d->tile.
 int pick_tile(const disyolo_conv_desc* d, int M) {
   if (d->tile > 0) return d->tile;
   const int N = d->Cout;
   const int K = d->ksize * d->ksize * (d->C0 + d->C1);
+  const bool k3 = d->ksize == 3;
   // narrow layers (the HBM-bound ends of the network): small tiles with the shallow pipeline,
   // i.e. the smallest LDS footprint and the most blocks per CU, win by 20-80 %
   if (N <= 32) return 4 | 0x200;
-  if (N <= 64) return (d->ksize == 3 ? 2 : 6) | 0x200;
-  if (M >= 40000 && K >= 576 && N % 128 == 0) return 8 | 0x100;
-  if (M < 4096) return 3 | 0x200;   // few blocks per CU: the deeper pipeline pays
+  if (N <= 64) return (k3 ? 2 : 6) | 0x200;
+  if (M < 4096) return (k3 && N >= 1024) ? (3 | 0x200) : 6;
+  if (M >= 40000 && N % 128 == 0)
+    return (K >= 128 && ceil_div(M, 192) * (N / 128) >= 300) ? 12 : (2 | 0x200);
+  if (!k3 && M < 20000) return N >= 512 ? 3 : 6;
   return 3;
 }
 
@@ -559,16 +641,18 @@ extern "C" int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d) {
 
 // stages per (tile id, BK, variant): keep in sync with DY_TILE in dispatch()
 static int tile_stages(int id, bool bk64, int variant) {
-  static const int tab[10][4] = {{0, 0, 0, 0}, {2, 3, 3, 4}, {3, 2, 4, 3}, {2, 3, 4, 3}, {3, 2, 4, 3},
-                                 {3, 2, 4, 3}, {3, 2, 4, 3}, {3, 2, 4, 3}, {2, 3, 3, 4}, {6, 4, 6, 4}};
+  static const int tab[16][4] = {{0, 0, 0, 0}, {2, 3, 3, 4}, {3, 2, 4, 3}, {2, 3, 4, 3}, {3, 2, 4, 3},
+                                 {3, 2, 4, 3}, {3, 2, 4, 3}, {3, 2, 4, 3}, {2, 3, 3, 4}, {6, 4, 6, 4},
+                                 {2, 3, 4, 3}, {4, 5, 6, 4}, {2, 3, 3, 4},
+                                 {2, 3, 2, 3}, {2, 2, 2, 2}, {2, 2, 2, 2}};
   return tab[id][(bk64 ? 0 : 2) + (variant ? 1 : 0)];
 }
 
 extern "C" int disyolo_conv2d_tile(const disyolo_conv_desc* d, int* bm, int* bn, int* bk, int* stages) {
   if (!d) return DISYOLO_E_ARG;
   const int sel = pick_tile(d, d->B * d->Ho * d->Wo);
-  const int id = sel & 0xff;
   const bool bk64 = (d->C0 % 64 == 0) && (d->C1 % 64 == 0) && !(sel & 0x100);
+  const int id = resolve_tile(sel & 0xff, bk64, d->ksize * d->ksize * (d->C0 + d->C1));
   for (const TileCfg& t : kTiles)
     if (t.id == id) {
       if (bm) *bm = t.bm;

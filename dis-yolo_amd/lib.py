@@ -225,6 +225,8 @@ def make_conv_desc(x0, w_packed, y, ksize, stride, *, x1=None, scale=None, shift
     d.ksize, d.stride, d.pad_t, d.pad_l, d.in_div = ksize, stride, pt, pl, in_div
     d.flags = (CONV_LEAKY if leaky else 0) | (CONV_OUT_F32 if out_f32 else 0) | (CONV_STATS if stats is not None else 0)
     d.alpha, d.tile = alpha, tile
+    if tile == 0 and TUNED:
+        d.tile = TUNED.get(conv_shape_key(d), 0)
     d.x0, d.x1, d.w = _p(x0), _p(x1), _p(w_packed)
     d.scale, d.shift, d.residual = _p(scale), _p(shift), _p(residual)
     d.y, d.stats = _p(y), _p(stats)
@@ -238,6 +240,70 @@ def conv2d_stats_rows(d: ConvDesc) -> int:
     if r < 0:
         raise DisyoloError("conv2d_stats_rows: bad descriptor")
     return r
+
+
+def conv_shape_key(d: ConvDesc):
+    """what the tile choice depends on: the GEMM shape and the gather variant (not the epilogue:
+    the batch-norm partial-sum rows are sized from a descriptor without one)"""
+    return (d.B, d.H, d.W, d.C0, d.C1, d.Ho, d.Wo, d.Cout, d.ksize, d.stride, d.in_div)
+
+
+# shape key -> tile code, filled by ConvTuner (YOLONet.autotune); consulted by make_conv_desc
+TUNED: dict = {}
+TUNE_CANDIDATES = (3, 0x203, 6, 0x206, 2, 0x202, 0x204, 10, 12, 0x108, 13, 0x20d, 14, 15)
+
+
+class ConvTuner:
+    """In-sequence tile autotuner.  Stand-alone timing loops keep a layer's operands hot in L2
+    and rank the tiles differently from how they behave inside the step (measured: DESIGN.md),
+    so the candidates are timed where they run: while ``active`` every conv2d_fwd launch is
+    bracketed with HIP events and uses the candidate of the current pass; the best candidate
+    per shape key goes to ``TUNED``."""
+
+    def __init__(self, candidates=TUNE_CANDIDATES):
+        self.candidates = tuple(candidates)
+        self.current = 0              # tile code of the running pass (0 = launcher heuristic)
+        self.events = {}              # (key, cand) -> [(start, end)]
+
+    def launch(self, d: ConvDesc) -> None:
+        key = conv_shape_key(d)
+        keep = d.tile
+        d.tile = self.current
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = load().disyolo_conv2d_fwd(C.byref(d), _stream())
+        e.record()
+        d.tile = keep
+        _check(rc, "conv2d_fwd")
+        self.events.setdefault((key, self.current), []).append((s, e))
+
+    def table(self):
+        """{key: {cand: median ms}}"""
+        torch.cuda.synchronize()
+        out = {}
+        for (key, cand), evs in self.events.items():
+            ts = sorted(s.elapsed_time(e) for s, e in evs)
+            out.setdefault(key, {})[cand] = ts[len(ts) // 2]
+        return out
+
+    def commit(self, min_gain: float = 0.02) -> dict:
+        """pick the fastest candidate per key; keep the heuristic unless beaten by min_gain"""
+        picks = {}
+        for key, row in self.table().items():
+            best = min(row, key=row.get)
+            base = row.get(0)
+            if base is not None and row[best] > base * (1.0 - min_gain):
+                best = 0
+            picks[key] = best
+            if best:
+                TUNED[key] = best
+            else:
+                TUNED.pop(key, None)
+        return picks
+
+
+TUNER: Optional[ConvTuner] = None
 
 
 class KernelTimer:
@@ -274,7 +340,8 @@ def conv_flops(d: ConvDesc) -> float:
     return 2.0 * d.B * d.Ho * d.Wo * d.Cout * K / float(d.in_div * d.in_div)
 
 
-_WAVES = {1: (2, 2), 2: (2, 2), 3: (2, 2), 4: (4, 1), 5: (4, 1), 6: (2, 2), 7: (4, 1), 8: (4, 2), 9: (2, 2)}
+_WAVES = {1: (2, 2), 2: (2, 2), 3: (2, 2), 4: (4, 1), 5: (4, 1), 6: (2, 2), 7: (4, 1), 8: (4, 2), 9: (2, 2),
+          10: (2, 2), 11: (2, 2), 12: (4, 2), 13: (2, 2), 14: (2, 2), 15: (4, 2)}
 
 
 def conv2d_tile(d: ConvDesc):
@@ -287,10 +354,14 @@ def conv2d_tile(d: ConvDesc):
 
 
 def conv2d_fwd(d: ConvDesc) -> None:
+    if TUNER is not None:
+        TUNER.launch(d)
+        return
     if TIMER is not None:
         if not hasattr(d, "_tname"):
             tid, bm, bn, bk, st = conv2d_tile(d)
-            d._tname = "conv_igemm_kernel<%d,%d,%d,%d,%d,%d,%d>" % ((bm, bn) + _WAVES[tid] + (bk, st, d.ksize))
+            d._tname = "conv_igemm_kernel<%d,%d,%d,%d,%d,%d,%d,%d>" % ((bm, bn) + _WAVES[tid] +
+                                                                        (bk, st, d.ksize, 2 if tid >= 13 else 1))
         TIMER.run(d._tname, conv_flops(d), lambda: _check(load().disyolo_conv2d_fwd(C.byref(d), _stream()),
                                                            "conv2d_fwd"))
         return

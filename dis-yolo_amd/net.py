@@ -724,6 +724,50 @@ class YOLONet(object):
                 on_layer_done(l)
         L.lane_sync(1, 0)
 
+    def autotune(self, reps: int = 3, candidates=None, det_thresh: float = cfg.OBJ_THRESHOLD) -> dict:
+        """Pick the conv tile per layer shape by timing the candidates inside the real layer
+        sequence (forward + backward, eager launches) on the batch currently set; training
+        state is saved and restored around it.  Call before ``build_program``.  Returns
+        {shape key: tile code} (0 = launcher heuristic kept)."""
+        if self._prog is not None:
+            raise L.DisyoloError("autotune() must run before build_program()")
+        state = {k: v.clone() for k, v in self.state_dict().items()} if self.training else None
+        # batch-norm partial sums are written per M tile: during tuning size them for the
+        # smallest BM of any candidate (results are not used, only in-bounds)
+        saved_stats = {}
+        for l in self.layers:
+            if l.stats is not None and l.idx > 1:
+                saved_stats[l.idx] = (l.stats, l.stats_rows)
+                l.stats = torch.zeros(-(-self.B * l.Ho * l.Wo // 64), l.cout, 2, dtype=F32, device=self.device)
+        if saved_stats:
+            self._build_descs()
+        tuner = L.ConvTuner(candidates or L.TUNE_CANDIDATES)
+        L.TUNED.clear()
+        L.TUNER = tuner
+        try:
+            for cand in (0,) + tuner.candidates:
+                tuner.current = cand
+                for _ in range(reps):
+                    if self.training:
+                        self.compute_losses(det_thresh)
+                        self.backward()
+                    else:
+                        self._forward_layers(False)
+            picks = tuner.commit()
+        finally:
+            L.TUNER = None
+            torch.cuda.synchronize()
+        # rebuild everything that depends on a tile: stats buffers (rows = M tiles), descriptors
+        for l in self.layers:
+            if l.idx in saved_stats:
+                l.stats = None
+        self._build_descs()
+        if self.training:
+            self._build_dgrad_descs()
+            self.load_state_dict(state)
+        self.tuned = picks
+        return picks
+
     @property
     def step_count(self) -> int:
         return int(self.step_dev.item())

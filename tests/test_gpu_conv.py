@@ -59,6 +59,21 @@ CASES = [
     (1, 12, 12, 32, 32, 3, 1, 6),          # 9 K-steps of BK=32
     (2, 12, 12, 64, 16, 1, 1, 5),          # nk = 1 (shorter than the pipeline depth)
     (2, 12, 12, 128, 64, 1, 1, 2),         # nk = 2
+    (2, 18, 18, 64, 128, 3, 1, 10),        # 96x128 tile (48x64 wave tiles), ragged last M tile
+    (2, 18, 18, 96, 128, 3, 1, 0x10a),     # ... at BK=32 (A tile padded to the DMA slab)
+    (4, 36, 36, 128, 256, 3, 1, 0x20b),    # ... deep pipeline variant
+    (2, 12, 12, 128, 128, 1, 1, 11),
+    (4, 36, 36, 128, 256, 3, 1, 12),       # 192x128 tile, 8 waves of 48x64
+    (2, 18, 18, 96, 128, 3, 1, 0x10c),
+    (2, 18, 18, 128, 256, 3, 1, 13),       # intra-block split-K (two K groups of 4 waves)
+    (2, 18, 18, 128, 256, 3, 1, 0x20d),
+    (4, 36, 36, 128, 256, 3, 1, 14),
+    (2, 18, 18, 192, 128, 3, 1, 14),       # 27 K slices: falls back to the plain 96x128 tile
+    (2, 18, 18, 192, 128, 1, 1, 13),       # 3 K slices: falls back
+    (2, 18, 18, 384, 128, 3, 1, 13),       # 6 channel slices per tap, groups interleave within a tap
+    (4, 36, 36, 128, 256, 3, 1, 15),       # 16 waves, all 160 KiB of LDS
+    (1, 16, 16, 1024, 512, 1, 1, 14),      # 1x1, split-K
+    (2, 12, 12, 96, 128, 3, 1, 14),        # falls back to the plain 96x128 tile (BK = 32)
 ]
 
 
@@ -138,7 +153,8 @@ def test_conv_residual_and_fused_concat(dev):
     check(y, want, 2.0 ** -7, 1e-3)
 
 
-def test_conv_stats_and_bn_finalize(dev):
+@pytest.mark.parametrize("tile", [0, 10, 12, 13, 14])
+def test_conv_stats_and_bn_finalize(dev, tile):
     """training BN: stats epilogue + finalize == tf.nn.moments (population variance) and the
     moving-average update of yolo/yolo3_net_pos.py:90-98."""
     g = torch.Generator().manual_seed(11)
@@ -147,10 +163,11 @@ def test_conv_stats_and_bn_finalize(dev):
     w = bf16r(torch.randn(3, 3, Cin, Cout, generator=g) / 24)
     raw = O.conv2d_same(x, w, 1)
     y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=dev)
-    d = L.make_conv_desc(x.to(torch.bfloat16).to(dev), pack_ref(w).to(torch.bfloat16).to(dev), y, 3, 1)
+    d = L.make_conv_desc(x.to(torch.bfloat16).to(dev), pack_ref(w).to(torch.bfloat16).to(dev), y, 3, 1, tile=tile)
     rows = L.conv2d_stats_rows(d)
     stats = torch.zeros(rows, Cout, 2, dtype=torch.float32, device=dev)
-    d = L.make_conv_desc(x.to(torch.bfloat16).to(dev), pack_ref(w).to(torch.bfloat16).to(dev), y, 3, 1, stats=stats)
+    d = L.make_conv_desc(x.to(torch.bfloat16).to(dev), pack_ref(w).to(torch.bfloat16).to(dev), y, 3, 1, stats=stats,
+                         tile=tile)
     L.conv2d_fwd(d)
     gamma = (torch.rand(Cout, generator=g) + 0.5).to(dev)
     beta = (torch.randn(Cout, generator=g) * 0.1).to(dev)

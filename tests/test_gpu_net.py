@@ -297,3 +297,35 @@ def test_device_shuffle_produces_fresh_uniform_permutations(dev):
     assert len({tuple(r) for r in seen[0]}) == B                   # and per image
     # 2560 draws of the first element: every value appears, none dominates
     assert first_pos.min() > 40 and first_pos.max() < 140
+
+
+def test_autotune_restores_state_and_keeps_results(dev):
+    """YOLONet.autotune() times tile candidates inside the layer sequence (garbage batch-norm sums
+    while it runs): afterwards every variable must be bit-identical to before, and a train step
+    with the tuned tiles must agree with the untuned net (same kernels per output element; only
+    the order of the batch-norm partial sums differs with the M tile)."""
+    B, S = 2, 64
+    b = O.synthetic_batch(B, S, seed=33)
+    ref = make_net(dev, True, 1, B=B, S=S, seed=8)
+    tuned = make_net(dev, True, 1, B=B, S=S, seed=8)
+    tuned.load_state_dict(ref.state_dict())
+    for n in (ref, tuned):
+        n.set_batch(b)
+    try:
+        picks = tuned.autotune(reps=1, det_thresh=0.1)
+        assert len(picks) > 10
+        for name in ref.params:
+            assert torch.equal(ref.params[name], tuned.params[name]), name
+        assert tuned.step_count == 0
+        l0 = float(ref.train_step(None, det_thresh=0.1).cpu())
+        tuned.build_program(det_thresh=0.1)
+        l1 = float(tuned.train_step(None).cpu())
+        assert abs(l0 - l1) <= 2e-3 * abs(l0), (l0, l1)
+        # inference-mode scores of the two nets after the step (moving statistics: no batch coupling)
+        for n in (ref, tuned):
+            n._forward_layers(False)
+        torch.cuda.synchronize()
+        a, c = ref.by_idx[75].act.float(), tuned.by_idx[75].act.float()
+        assert torch.allclose(a, c, rtol=0.05, atol=0.05)
+    finally:
+        L.TUNED.clear()
