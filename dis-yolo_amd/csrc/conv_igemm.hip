@@ -47,6 +47,12 @@ __device__ __forceinline__ int swz(int row, int chunk) {
   return chunk ^ ((row >> 1) & 7);
 }
 
+// 64-byte rows read at ANY row alignment (the patch kernel's tap-shifted pixel fragments): the
+// 4-entry table above is conflict-free only for fragments starting at a multiple of 16 rows;
+// XOR with 2*((row>>2)&1) is conflict-free for 16 consecutive rows from any start (the 8 tables
+// with that property, by exhaustive search, are all of this alternating form).
+__device__ __forceinline__ int swz_any(int row, int chunk) { return chunk ^ (((row >> 2) & 1) << 1); }
+
 // one LDS-DMA: 64 lanes x 16 B, buffer (descriptor + per-lane 32-bit byte offset) -> LDS
 // (wave-uniform base in M0 + lane*16).  Lanes whose offset is past the descriptor's range get
 // zeros written (hardware range check; probed on gfx950 with tools/probe_lds_dma.hip): that is
@@ -445,6 +451,59 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
   }
 
   if (!ep) return;
+  if (!(p.flags & DISYOLO_CONV_OUT_F32) && (p.Cout & 7) == 0) {
+    // bf16 output: every wave stages its WTM x WTN tile in LDS (rows padded by 16 B: the 8-byte
+    // writes of a 16-lane group and the 16-byte reads then spread over the banks) and writes
+    // it out as 16 B per lane, WTN*2 contiguous bytes per pixel -- whole 128-byte lines
+    // instead of the accumulator layout's 32-byte pieces of 16 different lines per store.
+    constexpr int ROWP = WTN * 2 + 16;
+    char* sw = smem + WM * BN * 8 + wave * (WTM * ROWP);   // behind the stats scratch
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + wn * WTN + j * 16 + cq * 4;
+      float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+      if (n < p.Cout) {   // Cout % 8 == 0 and n % 4 == 0: all four channels are in range
+        if (p.scale) *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(p.scale + n);
+        if (p.shift) *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(p.shift + n);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + px;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[i][j][r] * sc[r] + sh[r];
+          if (p.flags & DISYOLO_CONV_LEAKY) v[r] = leaky(v[r], p.alpha);
+        }
+        if (p.residual && m < p.M && n < p.Cout) {
+          const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.Cout + n);
+          v[0] += __builtin_bit_cast(float, rr.x << 16);
+          v[1] += __builtin_bit_cast(float, rr.x & 0xffff0000u);
+          v[2] += __builtin_bit_cast(float, rr.y << 16);
+          v[3] += __builtin_bit_cast(float, rr.y & 0xffff0000u);
+        }
+        uint2 o2;
+        o2.x = pack2(v[0], v[1]);
+        o2.y = pack2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(sw + (i * 16 + px) * ROWP + (j * 16 + cq * 4) * 2) = o2;
+      }
+    }
+    // written and read by the same wave: LDS ordering only, no block barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int CPR8 = WTN / 8, CH = WTM * CPR8;
+    bf16* yo = reinterpret_cast<bf16*>(p.y);
+#pragma unroll
+    for (int it = 0; it < (CH + 63) / 64; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / CPR8, ch = idx % CPR8;
+      const int m = m0 + wm * WTM + row, n = n0 + wn * WTN + ch * 8;
+      if (idx < CH && m < p.M && n < p.Cout)
+        *reinterpret_cast<uint4*>(yo + (size_t)m * p.Cout + n) = *reinterpret_cast<const uint4*>(sw + row * ROWP + ch * 16);
+    }
+    return;
+  }
   const bool vec_ok = (p.Cout & 3) == 0;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
@@ -502,6 +561,400 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution with halo reuse ("patch" kernel).
+//
+// The implicit-GEMM kernel above stages every input pixel once per filter tap (9x) and its
+// main loop is bound by the bytes a CU can stage per FLOP (global -> LDS ~50 B/clk/CU, each
+// 1 KiB LDS-DMA costing ~60 issue cycles; DESIGN.md "What bounds the conv kernel").  Here a
+// block owns a PH x PW patch of output pixels of ONE image and BN = 16*NI output channels:
+// per 32-channel slice it stages the (PH+2) x (PW+2) halo ONCE plus the 9 x BN x 32 weights,
+// then runs all 9 taps from LDS -- the tap shift is just a different LDS row per lane.
+// For an 18x18 patch x 64 channels that is 108 B staged per K element for 20,736 outputs,
+// against 192 B for 8,192 outputs of the 64x128 GEMM tile: 4.5x fewer bytes per FLOP, one
+// barrier per 32 input channels instead of one per 64 K elements, 9 DMAs per 108 MFMAs per wave.
+//
+// Waves: NW per block; M fragment f (16 consecutive patch pixels) belongs to wave f % NW, each
+// wave holds up to FW of them x NI channel fragments.  LDS per stage: halo [pixels][32 ch] +
+// weights [tap][BN][32], 64-byte rows, 16-byte chunks XOR-swizzled as in the GEMM kernel;
+// 2 stages (compute slice c while slice c+1 lands).
+template <int NW, int FW, int NI>
+__global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH, int PW, int tilesY, int tilesX) {
+  constexpr int BN = NI * 16;
+  constexpr int SLAB = NW * 1024;
+  constexpr int AIM = 4;                                        // halo DMAs per wave (<= 64*NW pixels)
+  constexpr int BIM = (9 * BN * 4 + NW * 64 - 1) / (NW * 64);   // weight DMAs per wave
+  constexpr int A_BYTES = AIM * SLAB;
+  constexpr int STB = (AIM + BIM) * SLAB;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int tile;
+  {  // XCD-aware order, channel tile fastest (blocks sharing a halo sit on one L2)
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int mt = tile / p.tilesN, nt = tile - mt * p.tilesN;
+  const int n0 = nt * BN;
+  const int tpi = tilesY * tilesX;             // patches per image
+  const int b = mt / tpi, pr = mt - b * tpi;
+  const int ty = pr / tilesX, tx = pr - ty * tilesX;
+  const int y0 = ty * PH, x0 = tx * PW;        // patch origin (output = input coordinates: SAME, stride 1)
+  const int HW_ = PW + 2, NPIX = (PH + 2) * HW_, NOUT = PH * PW;
+
+  const i32x4 srd0 = make_srd(p.x0, p.bytes0);
+  const i32x4 srdw = make_srd(p.w, p.bytesw);
+  // halo gather offsets (constant over the K loop; the channel slice goes into the SGPR offset)
+  unsigned a_off[AIM];
+#pragma unroll
+  for (int j = 0; j < AIM; ++j) {
+    const int chunk = (j * NW + wave) * 64 + lane;
+    const int hp = chunk >> 2, pc = chunk & 3;
+    int hy, hx;
+    divmod_small(hp < NPIX ? hp : 0, HW_, hy, hx);
+    const int iy = y0 + hy - p.pad_t, ix = x0 + hx - p.pad_l;
+    const bool ok = (hp < NPIX) && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
+    a_off[j] = ok ? (unsigned)(((b * p.H + iy) * p.W + ix) * p.C0) * 2u + swz_any(hp, pc) * 16 : OOB;
+  }
+  unsigned b_off[BIM];
+#pragma unroll
+  for (int j = 0; j < BIM; ++j) {
+    const int chunk = (j * NW + wave) * 64 + lane;
+    const int rb = chunk >> 2, pc = chunk & 3;     // row = tap*BN + n
+    const int tap = rb / BN, nl = rb - tap * BN;
+    const bool ok = (rb < 9 * BN) && (n0 + nl < p.Cout);
+    b_off[j] = ok ? ((unsigned)(n0 + nl) * (unsigned)p.K + (unsigned)(tap * p.Cin)) * 2u + swz_any(rb, pc) * 16 : OOB;
+  }
+  // DMA i of a slice: i < AIM halo, else weights.  The first slice is issued in one go; the
+  // following ones are spread over the 9 taps of the slice being multiplied, so a wave's DMA
+  // issue (~60 cycles each) overlaps its own MFMAs instead of preceding them.
+  constexpr int NDMA = AIM + BIM, DPT = (NDMA + 8) / 9;
+  auto issue_one = [&]<int I>(std::integral_constant<int, I>, int c, int stage) {
+    if constexpr (I < NDMA) {
+      const unsigned sbase = lds0 + stage * STB + wave * 1024;
+      const unsigned cs2 = (unsigned)c * 64u;      // 32 channels x 2 bytes
+      if constexpr (I < AIM)
+        dma16<I * SLAB>(a_off[I], srd0, cs2, sbase);
+      else
+        dma16<A_BYTES + (I - AIM) * SLAB>(b_off[I - AIM], srdw, cs2, sbase);
+    }
+  };
+  auto issue = [&](int c, int stage) {
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+      (issue_one(std::integral_constant<int, I>{}, c, stage), ...);
+    }(std::make_integer_sequence<int, NDMA>{});
+  };
+
+  // fragment read state
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const int nfrags = (NOUT + 15) >> 4;
+  int hp0[FW];          // halo pixel of this lane's patch pixel at tap (0,0), per M fragment
+  int q_of[FW];         // patch pixel index (or -1)
+#pragma unroll
+  for (int t = 0; t < FW; ++t) {
+    const int f = wave + NW * t;
+    const int q = f * 16 + frow;
+    const bool ok = q < NOUT;
+    int py, px;
+    divmod_small(ok ? q : 0, PW, py, px);
+    hp0[t] = py * HW_ + px;
+    q_of[t] = ok ? q : -1;
+  }
+  int nf_w = 0;  // fragments this wave owns (wave-uniform)
+#pragma unroll
+  for (int t = 0; t < FW; ++t) nf_w += (wave + NW * t < nfrags) ? 1 : 0;
+  nf_w = __builtin_amdgcn_readfirstlane(nf_w);
+  unsigned wb[NI];      // weight fragment byte address at tap 0 (the swizzle does not depend on the tap: BN % 16 == 0)
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int rb = j * 16 + frow;
+    wb[j] = A_BYTES + rb * 64 + swz_any(rb, fchunk) * 16;
+  }
+
+  f32x4 acc[FW][NI];
+#pragma unroll
+  for (int t = 0; t < FW; ++t)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nch = p.Cin >> 5;
+  issue(0, 0);
+  for (int c = 0; c < nch; ++c) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // slice c has landed for everyone; everyone is done with slice c-1
+    asm volatile("" ::: "memory");
+    const bool more = c + 1 < nch;
+    const char* st = smem + (c & 1) * STB;
+    auto tap_body = [&]<int TAP>(std::integral_constant<int, TAP>) {
+      constexpr int kh = TAP / 3, kw = TAP % 3;
+      bf16x8 wf[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(st + wb[j] + TAP * BN * 64);
+#pragma unroll
+      for (int t = 0; t < FW; ++t) {
+        if (t < nf_w) {
+          const int hp = hp0[t] + kh * HW_ + kw;
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(st + hp * 64 + swz_any(hp, fchunk) * 16);
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+#ifdef DY_PROBE
+            if (p.flags & 0x10000) {
+              asm volatile("" ::"v"(xf), "v"(wf[j]));
+              continue;
+            }
+#endif
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf, acc[t][j], 0, 0, 0);
+          }
+        }
+      }
+#ifdef DY_PROBE
+      if (p.flags & 0x4000) return;
+#endif
+      if (more) {
+        [&]<int... D>(std::integer_sequence<int, D...>) {
+          (issue_one(std::integral_constant<int, TAP * DPT + D>{}, c + 1, (c + 1) & 1), ...);
+        }(std::make_integer_sequence<int, DPT>{});
+      }
+    };
+    [&]<int... T>(std::integer_sequence<int, T...>) {
+      (tap_body(std::integral_constant<int, T>{}), ...);
+    }(std::make_integer_sequence<int, 9>{});
+  }
+  __syncthreads();
+
+  // ---- epilogue.  acc[t][j][r]: patch pixel q_of[t] (lane & 15), channel n0 + j*16 + 4*(lane>>4) + r
+  const int cq = lane >> 4;
+#ifdef DY_PROBE
+  if ((p.flags & 0x80000) && acc[0][0][0] != 123.456f) return;   // timing probe: no epilogue
+#endif
+  if (p.flags & DISYOLO_CONV_STATS) {
+    float* red = reinterpret_cast<float*>(smem);  // [NW][BN][2]
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < FW; ++t) {
+          const float v = (t < nf_w && q_of[t] >= 0) ? acc[t][j][r] : 0.f;
+          s += v;
+          s2 += v * v;
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          s += __shfl_xor(s, o, 64);
+          s2 += __shfl_xor(s2, o, 64);
+        }
+        if (frow == 0) {
+          const int nl = j * 16 + cq * 4 + r;
+          red[(wave * BN + nl) * 2 + 0] = s;
+          red[(wave * BN + nl) * 2 + 1] = s2;
+        }
+      }
+    }
+    __syncthreads();
+    for (int nl = tid; nl < BN; nl += NW * 64) {
+      const int n = n0 + nl;
+      if (n < p.Cout) {
+        float s = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w_ = 0; w_ < NW; ++w_) {
+          s += red[(w_ * BN + nl) * 2 + 0];
+          s2 += red[(w_ * BN + nl) * 2 + 1];
+        }
+        p.stats[((size_t)mt * p.Cout + n) * 2 + 0] = s;
+        p.stats[((size_t)mt * p.Cout + n) * 2 + 1] = s2;
+      }
+    }
+  }
+
+  if (!(p.flags & DISYOLO_CONV_OUT_F32) && (p.Cout & 7) == 0) {
+    // coalesced bf16 stores through a per-wave LDS staging tile (see the GEMM kernel's epilogue)
+    constexpr int ROWP = BN * 2 + 16;
+    char* sw = smem + NW * BN * 8 + wave * (FW * 16 * ROWP);
+    int m_of[FW];
+#pragma unroll
+    for (int t = 0; t < FW; ++t) {
+      int py, px;
+      divmod_small(q_of[t] >= 0 ? q_of[t] : 0, PW, py, px);
+      m_of[t] = (t < nf_w && q_of[t] >= 0) ? (b * p.Ho + y0 + py) * p.Wo + x0 + px : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + j * 16 + cq * 4;
+      float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+      if (n < p.Cout) {
+        if (p.scale) *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(p.scale + n);
+        if (p.shift) *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(p.shift + n);
+      }
+#pragma unroll
+      for (int t = 0; t < FW; ++t) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[t][j][r] * sc[r] + sh[r];
+          if (p.flags & DISYOLO_CONV_LEAKY) v[r] = leaky(v[r], p.alpha);
+        }
+        if (p.residual && m_of[t] >= 0 && n < p.Cout) {
+          const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)m_of[t] * p.Cout + n);
+          v[0] += __builtin_bit_cast(float, rr.x << 16);
+          v[1] += __builtin_bit_cast(float, rr.x & 0xffff0000u);
+          v[2] += __builtin_bit_cast(float, rr.y << 16);
+          v[3] += __builtin_bit_cast(float, rr.y & 0xffff0000u);
+        }
+        uint2 o2;
+        o2.x = pack2(v[0], v[1]);
+        o2.y = pack2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(sw + (t * 16 + frow) * ROWP + (j * 16 + cq * 4) * 2) = o2;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    bf16* yo = reinterpret_cast<bf16*>(p.y);
+    constexpr int CPR8 = BN / 8;   // 16-byte chunks per pixel row: 2 rounds of 64 lanes per fragment
+#pragma unroll
+    for (int t = 0; t < FW; ++t) {
+#pragma unroll
+      for (int it = 0; it < 16 * CPR8 / 64; ++it) {
+        const int idx = it * 64 + lane;
+        const int r16 = idx / CPR8, ch = idx % CPR8;
+        // the pixel of row r16 of this fragment lives in lane r16 (any cq) of m_of[t]
+        const int m = __shfl(m_of[t], r16, 64);
+        const int n = n0 + ch * 8;
+        if (m >= 0 && n < p.Cout)
+          *reinterpret_cast<uint4*>(yo + (size_t)m * p.Cout + n) =
+              *reinterpret_cast<const uint4*>(sw + (t * 16 + r16) * ROWP + ch * 16);
+      }
+    }
+    return;
+  }
+  const bool vec_ok = (p.Cout & 3) == 0;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = n0 + j * 16 + cq * 4;
+    if (n >= p.Cout) continue;
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (n + r < p.Cout) {
+        if (p.scale) sc[r] = p.scale[n + r];
+        if (p.shift) sh[r] = p.shift[n + r];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < FW; ++t) {
+      if (!(t < nf_w) || q_of[t] < 0) continue;
+      int py, px;
+      divmod_small(q_of[t], PW, py, px);
+      const int m = (b * p.Ho + y0 + py) * p.Wo + x0 + px;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[t][j][r] * sc[r] + sh[r];
+        if (p.flags & DISYOLO_CONV_LEAKY) v[r] = leaky(v[r], p.alpha);
+      }
+      const size_t off = (size_t)m * p.Cout + n;
+      if (vec_ok) {
+        if (p.residual) {
+          const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + off);
+          v[0] += __builtin_bit_cast(float, rr.x << 16);
+          v[1] += __builtin_bit_cast(float, rr.x & 0xffff0000u);
+          v[2] += __builtin_bit_cast(float, rr.y << 16);
+          v[3] += __builtin_bit_cast(float, rr.y & 0xffff0000u);
+        }
+        if (p.flags & DISYOLO_CONV_OUT_F32) {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + off) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          uint2 o;
+          o.x = pack2(v[0], v[1]);
+          o.y = pack2(v[2], v[3]);
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(p.y) + off) = o;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r < p.Cout) {
+            float o = v[r];
+            if (p.residual) o += (float)p.residual[off + r];
+            if (p.flags & DISYOLO_CONV_OUT_F32)
+              reinterpret_cast<float*>(p.y)[off + r] = o;
+            else
+              reinterpret_cast<bf16*>(p.y)[off + r] = (bf16)o;
+          }
+        }
+      }
+    }
+  }
+}
+
+// patch of the halo kernel for an H x W image: PH | H, PW | W, at most max_frags*16 output
+// pixels and max_halo halo pixels; the largest area wins, then the squarest.  0 = none fits.
+struct Patch {
+  int ph, pw;
+};
+Patch pick_patch(int H, int W, int max_frags, int max_halo) {
+  Patch best{0, 0};
+  int best_area = 0, best_halo = 1 << 30;
+  for (int ph = 1; ph <= H; ++ph) {
+    if (H % ph) continue;
+    for (int pw = 1; pw <= W; ++pw) {
+      if (W % pw) continue;
+      const int area = ph * pw, halo = (ph + 2) * (pw + 2);
+      if ((area + 15) / 16 > max_frags || halo > max_halo) continue;
+      if (area > best_area || (area == best_area && halo < best_halo)) {
+        best = Patch{ph, pw};
+        best_area = area;
+        best_halo = halo;
+      }
+    }
+  }
+  return best;
+}
+// halo tile ids: 16 = 8 waves x 3 fragments (up to 384 pixels: 18x18), 17 = 4 waves x 3
+// (up to 192 pixels: 9x18); both 64 output channels per block
+bool halo_cfg(int id, int& nw, int& fw) {
+  if (id == 16) { nw = 8; fw = 3; return true; }
+  if (id == 17) { nw = 4; fw = 3; return true; }
+  return false;
+}
+bool halo_ok(const disyolo_conv_desc* d, int id, Patch* out) {
+  int nw, fw;
+  if (!halo_cfg(id, nw, fw)) return false;
+  if (d->ksize != 3 || d->stride != 1 || d->in_div != 1 || d->C1 != 0 || d->C0 % 32 != 0) return false;
+  if (d->Ho != d->H || d->Wo != d->W) return false;
+  const Patch pt = pick_patch(d->H, d->W, nw * fw, 64 * nw);
+  if (pt.ph == 0 || pt.ph * pt.pw < 64) return false;
+  if (out) *out = pt;
+  return true;
+}
+template <int NW, int FW, int NI>
+int launch_halo(const ConvParams& p, Patch pt, hipStream_t s) {
+  ConvParams q = p;
+  constexpr int BN = NI * 16;
+  const int tilesY = p.H / pt.ph, tilesX = p.W / pt.pw;
+  q.tilesM = p.B * tilesY * tilesX;
+  q.tilesN = ceil_div(p.Cout, BN);
+  constexpr int SLAB = NW * 1024, BIM = (9 * BN * 4 + NW * 64 - 1) / (NW * 64);
+  const size_t lds = (size_t)2 * (4 + BIM) * SLAB;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<NW, FW, NI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_halo_kernel<NW, FW, NI>), dim3(q.tilesM * q.tilesN), dim3(NW * 64), lds, s, q, pt.ph,
+                     pt.pw, tilesY, tilesX);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+
 struct TileCfg {
   int id, bm, bn;
 };
@@ -526,6 +979,8 @@ int launch_ks(const ConvParams& p, hipStream_t s) {
   if (red > lds) lds = red;
   const size_t xg = (size_t)(KG - 1) * BM * BN * sizeof(float);
   if (xg > lds) lds = xg;
+  const size_t stg = red + (size_t)NW * (BM / WM) * ((BN / WN) * 2 + 16);   // epilogue staging behind the stats scratch
+  if (stg > lds) lds = stg;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, ST, KS, KG>),
@@ -589,8 +1044,7 @@ int dispatch(int id, bool bk64, int variant, const ConvParams& p, hipStream_t s)
 // (64x64 / 128x64) -- occupancy and short epilogues beat staging efficiency when a layer is
 // only ~10 us of MFMA work.  Returns id | flags: bit 8 = force BK 32, bit 9 = alternative
 // pipeline depth.  A caller that tunes for its own shapes passes the result in d->tile.
-int pick_tile(const disyolo_conv_desc* d, int M) {
-  if (d->tile > 0) return d->tile;
+int pick_auto(const disyolo_conv_desc* d, int M) {
   const int N = d->Cout;
   const int K = d->ksize * d->ksize * (d->C0 + d->C1);
   const bool k3 = d->ksize == 3;
@@ -603,6 +1057,11 @@ int pick_tile(const disyolo_conv_desc* d, int M) {
     return (K >= 128 && ceil_div(M, 192) * (N / 128) >= 300) ? 12 : (2 | 0x200);
   if (!k3 && M < 20000) return N >= 512 ? 3 : 6;
   return 3;
+}
+
+int pick_tile(const disyolo_conv_desc* d, int M) {
+  if (d->tile > 0) return d->tile;
+  return pick_auto(d, M);
 }
 
 int tile_bm(int id) {
@@ -634,7 +1093,13 @@ int validate(const disyolo_conv_desc* d) {
 extern "C" int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d) {
   if (!d) return DISYOLO_E_ARG;
   const int M = d->B * d->Ho * d->Wo;
-  const int bm = tile_bm(pick_tile(d, M) & 0xff);
+  int sel = pick_tile(d, M);
+  if ((sel & 0xff) >= 16) {
+    Patch pt;
+    if (halo_ok(d, sel & 0xff, &pt)) return d->B * (d->H / pt.ph) * (d->W / pt.pw);
+    sel = pick_auto(d, M);
+  }
+  const int bm = tile_bm(sel & 0xff);
   if (bm == 0) return DISYOLO_E_ARG;
   return ceil_div(M, bm);
 }
@@ -650,7 +1115,18 @@ static int tile_stages(int id, bool bk64, int variant) {
 
 extern "C" int disyolo_conv2d_tile(const disyolo_conv_desc* d, int* bm, int* bn, int* bk, int* stages) {
   if (!d) return DISYOLO_E_ARG;
-  const int sel = pick_tile(d, d->B * d->Ho * d->Wo);
+  int sel = pick_tile(d, d->B * d->Ho * d->Wo);
+  if ((sel & 0xff) >= 16) {
+    Patch pt;
+    if (halo_ok(d, sel & 0xff, &pt)) {
+      if (bm) *bm = pt.ph * pt.pw;
+      if (bn) *bn = 64;
+      if (bk) *bk = 32;
+      if (stages) *stages = 2;
+      return sel & 0xff;
+    }
+    sel = pick_auto(d, d->B * d->Ho * d->Wo);
+  }
   const bool bk64 = (d->C0 % 64 == 0) && (d->C1 % 64 == 0) && !(sel & 0x100);
   const int id = resolve_tile(sel & 0xff, bk64, d->ksize * d->ksize * (d->C0 + d->C1));
   for (const TileCfg& t : kTiles)
@@ -697,7 +1173,13 @@ extern "C" int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   // tile field: low byte = tile id (0 = auto); bit 8 forces BK = 32, bit 9 selects the
   // alternative pipeline depth (tuning / testing)
-  const int sel = pick_tile(d, p.M);
+  int sel = pick_tile(d, p.M);
+  if ((sel & 0xff) >= 16) {
+    Patch pt;
+    if (halo_ok(d, sel & 0xff, &pt))
+      return (sel & 0xff) == 16 ? launch_halo<8, 3, 4>(p, pt, s) : launch_halo<4, 3, 4>(p, pt, s);
+    sel = pick_auto(d, p.M);   // shape not covered by the patch kernel
+  }
   const bool bk64 = (d->C0 % 64 == 0) && (d->C1 % 64 == 0) && !(sel & 0x100);
   return dispatch(sel & 0xff, bk64, (sel >> 9) & 1, p, s);
 }

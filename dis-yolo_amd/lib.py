@@ -250,7 +250,7 @@ def conv_shape_key(d: ConvDesc):
 
 # shape key -> tile code, filled by ConvTuner (YOLONet.autotune); consulted by make_conv_desc
 TUNED: dict = {}
-TUNE_CANDIDATES = (3, 0x203, 6, 0x206, 2, 0x202, 0x204, 10, 12, 0x108, 13, 0x20d, 14, 15)
+TUNE_CANDIDATES = (3, 0x203, 6, 0x206, 2, 0x202, 0x204, 10, 12, 0x108, 0x20d, 16, 17)
 
 
 class ConvTuner:
@@ -360,8 +360,11 @@ def conv2d_fwd(d: ConvDesc) -> None:
     if TIMER is not None:
         if not hasattr(d, "_tname"):
             tid, bm, bn, bk, st = conv2d_tile(d)
-            d._tname = "conv_igemm_kernel<%d,%d,%d,%d,%d,%d,%d,%d>" % ((bm, bn) + _WAVES[tid] +
-                                                                        (bk, st, d.ksize, 2 if tid >= 13 else 1))
+            if tid >= 16:
+                d._tname = "conv_halo_kernel<%d,3,4>" % (8 if tid == 16 else 4)
+            else:
+                d._tname = "conv_igemm_kernel<%d,%d,%d,%d,%d,%d,%d,%d>" % ((bm, bn) + _WAVES[tid] +
+                                                                            (bk, st, d.ksize, 2 if tid >= 13 else 1))
         TIMER.run(d._tname, conv_flops(d), lambda: _check(load().disyolo_conv2d_fwd(C.byref(d), _stream()),
                                                            "conv2d_fwd"))
         return

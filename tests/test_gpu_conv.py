@@ -74,6 +74,13 @@ CASES = [
     (4, 36, 36, 128, 256, 3, 1, 15),       # 16 waves, all 160 KiB of LDS
     (1, 16, 16, 1024, 512, 1, 1, 14),      # 1x1, split-K
     (2, 12, 12, 96, 128, 3, 1, 14),        # falls back to the plain 96x128 tile (BK = 32)
+    (2, 18, 18, 64, 128, 3, 1, 16),        # halo-reuse patch kernel: one 18x18 patch per image, 8 waves
+    (1, 36, 36, 64, 64, 3, 1, 16),         # four patches per image
+    (2, 18, 18, 64, 128, 3, 1, 17),        # 9x18 patches, 4 waves
+    (1, 26, 26, 32, 96, 3, 1, 16),         # 13x26 patches (832^2 network), ragged channel tile, one K slice
+    (2, 20, 24, 96, 64, 3, 1, 16),         # 20x12 patches, three K slices
+    (1, 20, 20, 32, 64, 3, 2, 16),         # stride 2: not covered, falls back to the GEMM kernel
+    (3, 9, 9, 256, 256, 3, 1, 16),         # 9x9 patch = whole image, 6 of 24 fragment slots used
 ]
 
 
@@ -126,6 +133,35 @@ def test_conv_out_f32_bias_small_n(dev):
         check(y, want, 1e-5, 1e-4 * float(want.abs().max()))
 
 
+@pytest.mark.parametrize("tile", [16, 17])
+def test_conv_halo_residual_f32_and_pads(dev, tile):
+    """patch kernel epilogue variants: residual add, f32 output with bias, and the data-gradient
+    use (explicit pads, accumulate into an existing gradient through the residual pointer)"""
+    g = torch.Generator().manual_seed(70 + tile)
+    x = bf16r(torch.randn(2, 18, 36, 64, generator=g))
+    w = bf16r(torch.randn(3, 3, 64, 72, generator=g) / 24)
+    res = bf16r(torch.randn(2, 18, 36, 72, generator=g))
+    xd, wd = x.to(torch.bfloat16).to(dev), pack_ref(w).to(torch.bfloat16).to(dev)
+    y = torch.empty(2, 18, 36, 72, dtype=torch.bfloat16, device=dev)
+    d = L.make_conv_desc(xd, wd, y, 3, 1, residual=res.to(torch.bfloat16).to(dev), leaky=True, tile=tile)
+    assert L.conv2d_tile(d)[0] == tile
+    L.conv2d_fwd(d)
+    torch.cuda.synchronize()
+    check(y, O.leaky_relu(O.conv2d_same(x, w, 1), 0.1) + res, 2.0 ** -7, 1e-3)
+    bias = torch.randn(72, generator=g)
+    yf = torch.empty(2, 18, 36, 72, dtype=torch.float32, device=dev)
+    d = L.make_conv_desc(xd, wd, yf, 3, 1, shift=bias.to(dev), out_f32=True, tile=tile)
+    L.conv2d_fwd(d)
+    torch.cuda.synchronize()
+    want = O.conv2d_same(x, w, 1) + bias.double()
+    check(yf, want, 1e-5, 1e-4 * float(want.abs().max()))
+    d = L.make_conv_desc(xd, wd, y, 3, 1, pads=(1, 1), out_hw=(18, 36), residual=y, tile=tile)   # y += conv
+    before = y.float().cpu().double()
+    L.conv2d_fwd(d)
+    torch.cuda.synchronize()
+    check(y, before + O.conv2d_same(x, w, 1), 2.0 ** -7, 2e-3)
+
+
 def test_conv_residual_and_fused_concat(dev):
     g = torch.Generator().manual_seed(7)
     # residual (res_conv_bn, yolo/yolo3_net_pos.py:148-151): add AFTER the activation
@@ -153,7 +189,7 @@ def test_conv_residual_and_fused_concat(dev):
     check(y, want, 2.0 ** -7, 1e-3)
 
 
-@pytest.mark.parametrize("tile", [0, 10, 12, 13, 14])
+@pytest.mark.parametrize("tile", [0, 10, 12, 13, 14, 16, 17])
 def test_conv_stats_and_bn_finalize(dev, tile):
     """training BN: stats epilogue + finalize == tf.nn.moments (population variance) and the
     moving-average update of yolo/yolo3_net_pos.py:90-98."""
