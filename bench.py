@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--autotune", default="on", choices=("on", "off"),
                     help="time the conv tile candidates inside the layer sequence before recording the step "
                          "(setup, outside the timed region)")
+    ap.add_argument("--tune-cache", default=None, help="JSON file to load the autotuned tiles from / save them to")
     ap.add_argument("--force-dp", action="store_true",
                     help="initialise RCCL and run the bucketed gradient all-reduce path even with one rank (self-test)")
     ap.add_argument("--mode", default="auto", choices=("auto", "graph", "program", "eager"),
@@ -194,7 +195,7 @@ def main():
     gen = None                     # default CUDA generator
     if args.autotune == "on":
         t_tune = time.perf_counter()
-        picks = net.autotune()
+        picks = net.autotune(cache=args.tune_cache)
         if rank == 0:
             print("autotune %.1f s: %d of %d conv shapes moved off the launcher heuristic"
                   % (time.perf_counter() - t_tune, sum(1 for v in picks.values() if v), len(picks)), file=sys.stderr)

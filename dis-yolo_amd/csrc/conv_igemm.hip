@@ -1048,6 +1048,16 @@ int pick_auto(const disyolo_conv_desc* d, int M) {
   const int N = d->Cout;
   const int K = d->ksize * d->ksize * (d->C0 + d->C1);
   const bool k3 = d->ksize == 3;
+  // 3x3 stride-1 layers with >= 128 input channels: the patch kernel (halo staged once per 32
+  // channels instead of once per tap) wins when its grid is one full round of the 256 CUs, or
+  // when the layer is narrow (N <= 64) and the GEMM tiles are bound by staging
+  if (k3 && d->C0 >= 128) {
+    Patch pt;
+    if (halo_ok(d, 16, &pt)) {
+      const int blocks = d->B * (d->H / pt.ph) * (d->W / pt.pw) * ceil_div(N, 64);
+      if ((blocks >= 192 && blocks <= 256) || (N <= 64 && M >= 40000)) return 16;
+    }
+  }
   // narrow layers (the HBM-bound ends of the network): small tiles with the shallow pipeline,
   // i.e. the smallest LDS footprint and the most blocks per CU, win by 20-80 %
   if (N <= 32) return 4 | 0x200;

@@ -235,8 +235,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
   }
 
-  // D: row (K index) = 4*(lane>>4) + r, col (co) = lane&15
+  // D: row (K index) = 4*(lane>>4) + r, col (co) = lane&15.  Each wave stages its WTM x WTN f32
+  // tile in LDS (row pitch + 16 B) and writes it out 16 B per lane, WTN*4 contiguous bytes per K
+  // row, instead of 64-byte pieces of four rows per store.
   float* slab = p.out + (size_t)blockIdx.z * p.K * p.Cout;
+  __syncthreads();   // every wave is done with the operand stages
+  constexpr int ROWP = WTN * 4 + 16;
+  constexpr int HALF = MI / 2 * 16;                     // rows staged per round (two rounds)
+  if constexpr (NW * HALF * ROWP <= ST * STB) {
+    if ((p.Cout & 3) == 0) {
+      char* sw = smem + wave * (HALF * ROWP);
+      constexpr int CPR4 = WTN / 4, CH = HALF * CPR4;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i2 = 0; i2 < MI / 2; ++i2)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              *reinterpret_cast<float*>(sw + (i2 * 16 + g * 4 + r) * ROWP + (j * 16 + li) * 4) = acc[h * (MI / 2) + i2][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < (CH + 63) / 64; ++it) {
+          const int idx = it * 64 + lane;
+          const int row = idx / CPR4, ch = idx % CPR4;
+          const int kk = kt0 + wm * WTM + h * HALF + row, n = n0 + wn * WTN + ch * 4;
+          if (idx < CH && kk < p.K && n < p.Cout)
+            *reinterpret_cast<float4*>(slab + (size_t)kk * p.Cout + n) =
+                *reinterpret_cast<const float4*>(sw + row * ROWP + ch * 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
 #pragma unroll

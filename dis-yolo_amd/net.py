@@ -16,6 +16,7 @@ from __future__ import annotations
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import math
+import json
 import os
 import numpy as np
 import torch
@@ -157,6 +158,8 @@ class YOLONet(object):
         self._side_stream = None
         self._progs = None      # [parity] -> (list, marks, bwd_end) of the pipelined step
         self.use_side_lane = os.environ.get("DISYOLO_SIDE_LANE", "1") != "0"
+        # weight gradients of the last layers of the backward pass stay on the main lane (tuned below)
+        self.tail_on_main = int(os.environ.get("DISYOLO_TAIL_MAIN", "0"))
         self._init_params(seed, xavier_locked)
         self._plan(self.batchsize, self.image_size)
 
@@ -670,7 +673,9 @@ class YOLONet(object):
         # lane still runs the detection filter and the mask loss; the mask subnet follows.
         heads = [self.by_idx[i] for i in (75, 74, 67, 66, 59, 58)]
         rest = [l for l in reversed(self.layers) if l.idx not in self.HEAD_LAYERS]
+        order = [l for l in heads + rest if not l.lock]
         for l in heads + rest:
+            pos = order.index(l) if not l.lock else -1
             if l.idx == 82 and getattr(self, "_mask_loss_pending", False):
                 L.lane_sync(1, 0)          # dscore comes from the side lane
                 self._mask_loss_pending = False
@@ -695,7 +700,9 @@ class YOLONet(object):
             # the weight gradient is off the critical chain (dx -> dgrad -> next layer's BN
             # backward): in a recorded step it runs on the side lane, overlapping the small
             # latency-bound BN kernels of the following layers
-            side = self.use_side_lane
+            # ... except for the last few layers of the pass: nothing is left on the main lane to
+            # overlap with, the step would only wait for the side lane's backlog to drain
+            side = self.use_side_lane and (pos < len(order) - self.tail_on_main)
             if side:
                 L.lane_sync(0, 1)
                 L.set_lane(1)
@@ -724,13 +731,32 @@ class YOLONet(object):
                 on_layer_done(l)
         L.lane_sync(1, 0)
 
-    def autotune(self, reps: int = 3, candidates=None, det_thresh: float = cfg.OBJ_THRESHOLD) -> dict:
+    def _apply_tiles(self) -> None:
+        """rebuild everything that depends on a tile choice: batch-norm partial-sum buffers
+        (one row per M tile) and the conv descriptors"""
+        for l in self.layers:
+            if l.stats is not None and l.idx > 1:
+                l.stats = None
+        self._build_descs()
+        if self.training:
+            self._build_dgrad_descs()
+
+    def autotune(self, reps: int = 3, candidates=None, det_thresh: float = cfg.OBJ_THRESHOLD, cache=None) -> dict:
         """Pick the conv tile per layer shape by timing the candidates inside the real layer
         sequence (forward + backward, eager launches) on the batch currently set; training
         state is saved and restored around it.  Call before ``build_program``.  Returns
-        {shape key: tile code} (0 = launcher heuristic kept)."""
+        {shape key: tile code} (0 = launcher heuristic kept).  ``cache``: a JSON file the picks
+        are loaded from when present (no timing passes) and written to otherwise."""
         if self._prog is not None:
             raise L.DisyoloError("autotune() must run before build_program()")
+        if cache and os.path.exists(cache):
+            with open(cache) as f:
+                picks = {tuple(json.loads(k)): int(v) for k, v in json.load(f).items()}
+            L.TUNED.clear()
+            L.TUNED.update({k: v for k, v in picks.items() if v})
+            self._apply_tiles()
+            self.tuned = picks
+            return picks
         state = {k: v.clone() for k, v in self.state_dict().items()} if self.training else None
         # batch-norm partial sums are written per M tile: during tuning size them for the
         # smallest BM of any candidate (results are not used, only in-bounds)
@@ -757,15 +783,13 @@ class YOLONet(object):
         finally:
             L.TUNER = None
             torch.cuda.synchronize()
-        # rebuild everything that depends on a tile: stats buffers (rows = M tiles), descriptors
-        for l in self.layers:
-            if l.idx in saved_stats:
-                l.stats = None
-        self._build_descs()
+        self._apply_tiles()
         if self.training:
-            self._build_dgrad_descs()
             self.load_state_dict(state)
         self.tuned = picks
+        if cache:
+            with open(cache, "w") as f:
+                json.dump({json.dumps(list(k)): v for k, v in picks.items()}, f)
         return picks
 
     @property
