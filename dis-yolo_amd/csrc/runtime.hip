@@ -48,12 +48,18 @@ int dy_record(std::function<int(void*)> fn) {
 extern "C" void* disyolo_cmdlist_create(void) {
   CmdList* c = new CmdList();
   bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
-  // lane 2 carries work that must only fill the other lanes' bubbles (the next step's backbone):
-  // lowest stream priority
+  // lane 1 (weight gradients, detection filter, mask loss) runs beside the critical chain on the
+  // caller's stream: lowest stream priority, so the chain's kernels get the CU slots first when
+  // both have blocks pending (+1.5-2 % measured).  DISYOLO_LANE1_LOW=0 keeps it at normal priority
+  // (the data-parallel step does: its RCCL all-reduces are issued on this lane).
+  // lane 2 carries work that must only fill the other lanes' bubbles (the next step's backbone)
   int least = 0, greatest = 0;
+  const char* l1 = getenv("DISYOLO_LANE1_LOW");
+  const bool lane1_low = !(l1 && l1[0] == '0');
   if (ok) ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
   for (int i = 1; i < NLANES && ok; ++i)
-    ok = hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking, (i == 2 && getenv("DISYOLO_LANE2_LOW")) ? least : 0) == hipSuccess &&
+    ok = hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking,
+                                     ((i == 2 && getenv("DISYOLO_LANE2_LOW")) || (i == 1 && lane1_low)) ? least : 0) == hipSuccess &&
          hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
   if (!ok)  // no device (CPU-only build check): lists can still be recorded, not run
     for (int i = 1; i < NLANES; ++i) c->side[i] = nullptr;

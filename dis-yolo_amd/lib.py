@@ -250,7 +250,7 @@ def conv_shape_key(d: ConvDesc):
 
 # shape key -> tile code, filled by ConvTuner (YOLONet.autotune); consulted by make_conv_desc
 TUNED: dict = {}
-TUNE_CANDIDATES = (3, 0x203, 6, 0x206, 2, 0x202, 0x204, 10, 12, 0x108, 0x20d, 16, 17)
+TUNE_CANDIDATES = (3, 0x203, 6, 0x206, 2, 0x202, 0x204, 10, 12, 0x20c, 0x10c, 0x108, 0x20d, 16, 17)
 
 
 class ConvTuner:

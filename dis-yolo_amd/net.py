@@ -875,6 +875,9 @@ class YOLONet(object):
     def _record_step(self, det_thresh: float, parity):
         """one recorded step; parity None = plain, 0/1 = pipelined (consumes backbone outputs of
         that parity, produces the other)"""
+        if self.dp is not None:
+            # the RCCL all-reduces are issued on the side lane: keep it at normal stream priority
+            os.environ.setdefault("DISYOLO_LANE1_LOW", "0")
         prog = L.CmdList()
         marks = []
         with prog:
