@@ -288,11 +288,11 @@ def main():
             achieved = r["flops_total"] / (r["ms_total"] * 1e-3) / 1e12
             traffic, traffic_src = None, None
             try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc, see the file's "method")
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")))
                 key = dom.replace(",", ", ")
                 if key in pmc["kernels"]:
                     traffic = pmc["kernels"][key]["hbm_mb_per_launch_corrected"] * 1e6
-                    traffic_src = "profiles/r01f_pmc_traffic.json"
+                    traffic_src = "profiles/r01h_pmc_traffic.json"
             except Exception:
                 pass
             out["roofline"] = {"bound": "mfma", "kernel": dom, "timed_with": "HIP events, %d eager steps of the same workload" % args.steps, "achieved": round(achieved, 1),

@@ -1036,7 +1036,7 @@ int dispatch(int id, bool bk64, int variant, const ConvParams& p, hipStream_t s)
 
 // Launcher heuristic = the consensus of the in-sequence autotuner (YOLONet.autotune, which
 // times every candidate where it runs: inside the step, operands as cold as they really are)
-// over the layer shapes of the B = 8, 576^2 network; profiles/r01g_autotune.txt.  Stand-alone
+// over the layer shapes of the B = 8, 576^2 network; profiles/r01h_autotune.txt.  Stand-alone
 // timing loops (tools/bench_conv.py) keep a layer's operands hot in L2 and rank the tiles
 // differently -- rules taken from them measured 1-3 % SLOWER end to end.  What the picks say:
 // huge-M layers want the 8-wave 192x128 tile (48x64 wave tiles: fewest bytes staged per
