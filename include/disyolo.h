@@ -61,7 +61,13 @@ typedef struct disyolo_conv_desc {
                              where (yo*stride + kh - pad_t) is divisible by in_div    */
   int32_t flags;          /* DISYOLO_CONV_*                                           */
   float alpha;            /* leaky slope                                              */
-  int32_t tile;           /* 0 = auto; else tile-config id (tuning/testing)          */
+  int32_t tile;           /* 0 = the launcher's heuristic; else a tile code a caller-side
+                             tuner pins (what YOLONet.autotune does): low byte = id
+                             (1-12 GEMM block tiles 64x64 ... 256x128, 13-15 the same
+                             with two K groups per block, 16/17 the 3x3 stride-1 patch
+                             kernel with 8/4 waves; an id that does not cover the shape
+                             falls back), bit 8 = force K depth 32, bit 9 = the tile's
+                             alternative pipeline depth                              */
   const void* x0;         /* bf16 [B,H,W,C0]                                          */
   const void* x1;         /* bf16 [B,H/2,W/2,C1]: nearest-upsampled x2 and concatenated
                              after x0 along channels (1x1 convs only), or NULL        */
@@ -78,7 +84,8 @@ int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d);
 int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream);
 /* tile configuration the launcher picks for this descriptor: returns its id (> 0) and the
  * block tile (pixels x channels), K depth and pipeline stages -- the template arguments of the
- * conv_igemm_kernel instance that will run; bench.py attributes time per instance with it */
+ * conv_igemm_kernel instance that will run (ids 16/17: the conv_halo_kernel patch, 64
+ * channels, 32-channel slices, 2 stages); bench.py attributes time per instance with it */
 int disyolo_conv2d_tile(const disyolo_conv_desc* d, int* bm, int* bn, int* bk, int* stages);
 
 /* first layer (Cin=3, k=3, s=1; yolo/yolo3_net_pos.py:159): f32 NHWC image in, exact f32
