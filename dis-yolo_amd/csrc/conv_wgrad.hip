@@ -7,7 +7,7 @@
 // Both operands live in memory with the *reduction* index (pixel) as the slow dimension
 // (NHWC), so the LDS tiles are [pixel][k] / [pixel][co] images read back with the gfx950
 // transposing load ds_read_b64_tr_b16 straight into v_mfma_f32_16x16x32_bf16 fragments.
-// The pixel range is split over blockIdx.z; each split writes an f32 slab and a second
+// The pixel range is split over the grid (K tile fastest, XCD-aware order); each split writes an f32 slab and a second
 // kernel adds the slabs in a fixed order (deterministic, no float atomics).
 #include "common.h"
 #include "runtime.h"
@@ -24,6 +24,7 @@ struct WgradParams {
   int ks, stride, pad_t, pad_l;
   int M, K;
   int steps_per_split, steps;
+  int tilesK, tilesN;
   unsigned bytes0, bytes1, bytesy;
 };
 
@@ -86,9 +87,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int kt0 = blockIdx.x * BM;  // first K index of this block
-  const int n0 = blockIdx.y * BN;
-  const int step0 = blockIdx.z * p.steps_per_split;
+  // XCD-aware block order (blocks b and b+8 share an XCD and its L2): every XCD gets a contiguous
+  // run of work items with the K tile fastest, so the blocks that read the same dy tile (same
+  // channel tile and pixel split, all K tiles) sit on one L2 instead of filling all eight
+  int lin;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int bkt = lin % p.tilesK, brest = lin / p.tilesK;
+  const int bnt = brest % p.tilesN, bsplit = brest / p.tilesN;
+  const int kt0 = bkt * BM;  // first K index of this block
+  const int n0 = bnt * BN;
+  const int step0 = bsplit * p.steps_per_split;
   int step1 = step0 + p.steps_per_split;
   if (step1 > p.steps) step1 = p.steps;
   const int nsteps = step1 - step0;
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
   // D: row (K index) = 4*(lane>>4) + r, col (co) = lane&15.  Each wave stages its WTM x WTN f32
   // tile in LDS (row pitch + 16 B) and writes it out 16 B per lane, WTN*4 contiguous bytes per K
   // row, instead of 64-byte pieces of four rows per store.
-  float* slab = p.out + (size_t)blockIdx.z * p.K * p.Cout;
+  float* slab = p.out + (size_t)bsplit * p.K * p.Cout;
   __syncthreads();   // every wave is done with the operand stages
   constexpr int ROWP = WTN * 4 + 16;
   constexpr int HALF = MI / 2 * 16;                     // rows staged per round (two rounds)
@@ -396,7 +408,9 @@ extern "C" int disyolo_conv2d_wgrad(const disyolo_conv_desc* d, const void* dy, 
   plan(d, &bn, &splits, &p.steps_per_split, &p.steps);
   p.out = splits == 1 ? dw : (float*)workspace;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(ceil_div(p.K, 128), ceil_div(p.Cout, bn), splits);
+  p.tilesK = ceil_div(p.K, 128);
+  p.tilesN = ceil_div(p.Cout, bn);
+  dim3 grid(p.tilesK * p.tilesN * splits);
   // pipeline depth: d->tile (1..3 -> 2..4 stages) overrides the default (tuning)
   const int st = (d->tile >= 1 && d->tile <= 3) ? d->tile + 1 : 3;
 #define DY_WG(BNV, YB)                                                                                   \
