@@ -180,7 +180,13 @@ def main():
     if use_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        # the gradient all-reduces run on RCCL's own stream: give it high priority so the exchange
+        # is not starved by the backward pass it overlaps
+        try:
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, pg_options=opts)
+        except (AttributeError, TypeError):
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     B, S = args.batch, args.size
     if args.task == "infer":
