@@ -265,6 +265,15 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
     for (int g = 0; g < KG; ++g) advance();
   };
 
+  // the epilogue's per-channel scale/shift: fetched now (one channel per thread, two registers held
+  // through the loop) and handed over through LDS after the loop, so their load latency is not
+  // part of the epilogue of these ~10 us kernels
+  float pf_sc = 1.f, pf_sh = 0.f;
+  if (tid < BN && n0 + tid < p.Cout) {
+    if (p.scale) pf_sc = p.scale[n0 + tid];
+    if (p.shift) pf_sh = p.shift[n0 + tid];
+  }
+
   f32x4 acc[MI][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -401,6 +410,12 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
     __syncthreads();
   }
   const bool ep = (KG == 1) || (kg == 0);   // only group 0 holds the full sums
+  float* scsh = reinterpret_cast<float*>(smem + WM * BN * 8);   // [2][BN] behind the stats scratch
+  if (tid < BN) {
+    scsh[tid] = pf_sc;
+    scsh[BN + tid] = pf_sh;
+  }
+  if (!(p.flags & DISYOLO_CONV_STATS)) __syncthreads();   // (the stats path below has its own barrier)
 
   // ---- epilogue.  acc[i][j][r]: pixel m0 + wm*WTM + i*16 + (lane&15),
   //      channel n0 + wn*WTN + j*16 + 4*(lane>>4) + r ----
@@ -457,15 +472,14 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
     // it out as 16 B per lane, WTN*2 contiguous bytes per pixel -- whole 128-byte lines
     // instead of the accumulator layout's 32-byte pieces of 16 different lines per store.
     constexpr int ROWP = WTN * 2 + 16;
-    char* sw = smem + WM * BN * 8 + wave * (WTM * ROWP);   // behind the stats scratch
+    char* sw = smem + WM * BN * 8 + BN * 8 + wave * (WTM * ROWP);   // behind the stats scratch and scale/shift
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int n = n0 + wn * WTN + j * 16 + cq * 4;
-      float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
-      if (n < p.Cout) {   // Cout % 8 == 0 and n % 4 == 0: all four channels are in range
-        if (p.scale) *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(p.scale + n);
-        if (p.shift) *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(p.shift + n);
-      }
+      const int nl = wn * WTN + j * 16 + cq * 4;
+      float sc[4], sh[4];
+      *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(scsh + nl);
+      *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(scsh + BN + nl);
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * WTM + i * 16 + px;
@@ -979,7 +993,7 @@ int launch_ks(const ConvParams& p, hipStream_t s) {
   if (red > lds) lds = red;
   const size_t xg = (size_t)(KG - 1) * BM * BN * sizeof(float);
   if (xg > lds) lds = xg;
-  const size_t stg = red + (size_t)NW * (BM / WM) * ((BN / WN) * 2 + 16);   // epilogue staging behind the stats scratch
+  const size_t stg = red + (size_t)BN * 8 + (size_t)NW * (BM / WM) * ((BN / WN) * 2 + 16);   // scale/shift + epilogue staging behind the stats scratch
   if (stg > lds) lds = stg;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
