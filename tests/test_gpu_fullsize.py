@@ -117,6 +117,33 @@ def test_conv_linearity_at_full_size(dev):
     assert float(y[0, 0, 0, 0]) == 4 * 32 and float(y[0, 0, 5, 0]) == 6 * 32 and float(y[0, 5, 5, 0]) == 9 * 32
 
 
+@pytest.mark.parametrize("H,Cin,Cout", [(36, 256, 512), (72, 128, 256), (18, 512, 1024)])
+def test_conv_kernel_families_agree_at_full_size(dev, H, Cin, Cout):
+    """the same 3x3 layer of the B=8 network through every kernel family -- GEMM tiles, split-K
+    groups, the halo-reuse patch kernel -- with integer-valued operands whose products and sums
+    are exact in f32: all summation orders must give the bit-identical f32 result, and the bf16
+    epilogue (scale/shift, leaky, residual) the bit-identical bf16 result."""
+    g = torch.Generator(device=dev).manual_seed(H)
+    x = torch.randint(-3, 4, (B, H, H, Cin), device=dev, generator=g).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (Cout, 9 * Cin), device=dev, generator=g).to(torch.bfloat16)
+    res = torch.randint(-8, 9, (B, H, H, Cout), device=dev, generator=g).to(torch.bfloat16)
+    scale = torch.full((Cout,), 2.0 ** -9, device=dev)
+    shift = torch.full((Cout,), 0.25, device=dev)
+    outs_f32, outs_bf16 = [], []
+    for tile in (3, 6, 10, 12, 0x20d, 14, 16, 17):
+        y = torch.empty(B, H, H, Cout, dtype=torch.float32, device=dev)
+        L.conv2d_fwd(L.make_conv_desc(x, w, y, 3, 1, out_f32=True, tile=tile))
+        yb = torch.empty(B, H, H, Cout, dtype=torch.bfloat16, device=dev)
+        L.conv2d_fwd(L.make_conv_desc(x, w, yb, 3, 1, scale=scale, shift=shift, residual=res, leaky=True, tile=tile))
+        outs_f32.append(y)
+        outs_bf16.append(yb)
+    torch.cuda.synchronize()
+    assert float(outs_f32[0].abs().max()) > 100          # a real reduction, not zeros
+    for y, yb in zip(outs_f32[1:], outs_bf16[1:]):
+        assert torch.equal(y, outs_f32[0])
+        assert torch.equal(yb, outs_bf16[0])
+
+
 def test_inference_masks_are_half_outside_boxes_at_full_size(dev):
     net = YOLONet(training=False, device=dev, image_size=S, batch_size=4, stage=1, seed=0)
     with torch.no_grad():

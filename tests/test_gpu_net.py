@@ -299,7 +299,7 @@ def test_device_shuffle_produces_fresh_uniform_permutations(dev):
     assert first_pos.min() > 40 and first_pos.max() < 140
 
 
-def test_autotune_restores_state_and_keeps_results(dev):
+def test_autotune_restores_state_and_keeps_results(dev, tmp_path):
     """YOLONet.autotune() times tile candidates inside the layer sequence (garbage batch-norm sums
     while it runs): afterwards every variable must be bit-identical to before.  Tuned tiles change
     the f32 summation order (split-K groups, the patch kernel's channel-slice-major K order, the
@@ -326,6 +326,15 @@ def test_autotune_restores_state_and_keeps_results(dev):
         for i in (59, 67, 75, 82):
             a, c = ref.by_idx[i].act.float(), tuned.by_idx[i].act.float()
             assert torch.allclose(a, c, rtol=0.02, atol=0.02 * float(a.abs().max())), i
+        # the picks survive a round trip through the cache file (no timing passes on load)
+        cache = str(tmp_path / "tiles.json")
+        again = make_net(dev, True, 1, B=B, S=S, seed=8)
+        again.set_batch(b)
+        tuned_table = dict(L.TUNED)
+        import json
+        with open(cache, "w") as f:
+            json.dump({json.dumps(list(k)): v for k, v in picks.items()}, f)
+        assert again.autotune(cache=cache) == picks and dict(L.TUNED) == tuned_table
         l0 = float(ref.train_step(None, det_thresh=0.1).cpu())
         tuned.build_program(det_thresh=0.1)
         l1 = float(tuned.train_step(None).cpu())
