@@ -88,6 +88,8 @@ def bench_infer(args, dev, world, rank):
     net = YOLONet(training=False, device=dev, image_size=S, batch_size=B, stage=1, seed=0)
     batch = synthetic_batch(B, S, seed=1234 + rank)
     net._set_inputs(batch["images"], batch["clip_window"])
+    if args.autotune == "on":
+        net.autotune()
     net.build_infer_program(graph=(args.mode in ("auto", "graph")))
     for _ in range(args.warmup):
         net.infer()
