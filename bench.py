@@ -41,6 +41,43 @@ TRAIN_GFLOP_PER_IMG_576 = {1: 210.0, 2: 398.0}
 MFMA_PEAK_TFLOPS = 2500.0      # bf16 dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 
 
+HBM_PEAK_TBS = 8.0             # spec; ~6.3 TB/s measured copy
+
+
+def bound_model(B: int, S: int, stage: int):
+    """t_bound = sum over the step's kernels of max(F/P_peak, bytes/BW_peak), with the
+    algorithmic bf16 bytes of every conv (in + weights + out [+ residual]; its data and weight
+    gradients likewise), the BN / activation passes (2 resp. 5 tensor passes per training-mode
+    layer) and Adam (28 B per parameter).  Returns seconds per step on one GPU."""
+    from disyolo_amd.net import build_topology
+    layers = build_topology(3, 3)
+    spatial = {0: S}
+    t = 0.0
+    n_train = 0
+    lock_upto = 52 if stage == 1 else 0
+
+    def conv_t(M, N, K, in_b, w_b, out_b):
+        return max(2.0 * M * N * K / (MFMA_PEAK_TFLOPS * 1e12), (in_b + w_b + out_b) / (HBM_PEAK_TBS * 1e12))
+
+    for l in layers:
+        H = spatial[l.src]
+        Ho, _ = L.same_pads(H, l.k, l.stride)
+        spatial[l.idx] = Ho
+        M, N, K = B * Ho * Ho, l.cout, l.k * l.k * l.cin
+        in_b, w_b, out_b = B * H * H * l.cin * 2, K * N * 2, M * N * 2
+        res_b = out_b if l.shortcut is not None else 0
+        t += conv_t(M, N, K, in_b, w_b, out_b + res_b)                       # forward
+        if l.idx > lock_upto:
+            n_train += K * N + (N if l.kind == "lin" else 2 * N)
+            t += conv_t(M, N, K, in_b + out_b, 0, K * N * 4)                  # weight gradient (f32 out)
+            if l.idx > lock_upto + 1:
+                t += conv_t(M, N, K, out_b, w_b, in_b)                        # data gradient
+            if l.kind != "lin":
+                t += (2 + 5) * out_b / (HBM_PEAK_TBS * 1e12)                  # BN fwd (raw->act) + bwd passes
+    t += 28.0 * n_train / (HBM_PEAK_TBS * 1e12)                               # Adam
+    return t
+
+
 def cpu_baseline(stage: int, size: int, budget_s: float = 25.0):
     """Reference CPU path stand-in: the oracle (torch-CPU f32 restatement of the reference
     graph; TensorFlow 1.x itself cannot run here) doing the same train step at
@@ -283,6 +320,10 @@ def main():
                             "achieved_tflops_per_gpu": round(train_gflop * value / world / 1e3, 1),
                             "frac_of_mfma_peak": round(train_gflop * value / world / 1e3 / MFMA_PEAK_TFLOPS, 4)},
         }
+        tb = bound_model(B, S, args.stage)
+        out["bound_model"] = {"t_bound_ms": round(tb * 1e3, 3), "achieved_vs_bound": round(tb * 1e3 / ms, 4),
+                              "definition": "sum over kernels of max(FLOP/2.5 PF, algorithmic bytes/8 TB/s): convs "
+                                            "fwd/dgrad/wgrad, BN passes, Adam (SURVEY.md 8d)"}
         if timer is not None:
             summ = timer.summary()
             kernels = {}
