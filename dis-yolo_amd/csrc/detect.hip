@@ -298,6 +298,52 @@ __global__ __launch_bounds__(256) void psroi_assemble_kernel(const float* score,
   }
 }
 
+// ---- evaluate(): mask post-processing (calculate_test_map.py:237-262) ----------------------
+// One thread per image pixel walks the image's detections in order: inside a detection's
+// destination rectangle it samples the cropped mask bilinearly with cv2.resize(INTER_LINEAR)
+// semantics (pixel centres aligned, border taps clamped with weight 0, horizontal then vertical
+// pass, every product and sum rounded to f32 separately -- no FMA, so the > 0.5 decision is the
+// same as the host restatement's), writes the per-detection bit and keeps the class of the last
+// covering detection for the merged class map.
+__global__ __launch_bounds__(256) void mask_paste_kernel(const float* masks, int n, int size, const int* rects,
+                                                         const int* classids, int H, int W, unsigned char* full,
+                                                         unsigned char* merged) {
+  const int64_t total = (int64_t)H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+    unsigned char mcls = 0;
+    for (int k = 0; k < n; ++k) {
+      const int* r = rects + k * 8;
+      const int cy1 = r[0], cx1 = r[1], cy2 = r[2], cx2 = r[3], y1 = r[4], x1 = r[5], y2 = r[6], x2 = r[7];
+      const int sh = cy2 - cy1, sw = cx2 - cx1, dh = y2 - y1, dw = x2 - x1;
+      unsigned char bit = 0;
+      if (sh > 0 && sw > 0 && dh > 0 && dw > 0 && y >= y1 && y < y2 && x >= x1 && x < x2) {
+        float fx = (float)(((double)(x - x1) + 0.5) * ((double)sw / (double)dw) - 0.5);
+        float fy = (float)(((double)(y - y1) + 0.5) * ((double)sh / (double)dh) - 0.5);
+        int sx = (int)floorf(fx), sy = (int)floorf(fy);
+        float ax = __fsub_rn(fx, (float)sx), ay = __fsub_rn(fy, (float)sy);
+        if (sx < 0) { ax = 0.f; sx = 0; }
+        if (sx >= sw - 1) { ax = 0.f; sx = sw - 1; }
+        if (sy < 0) { ay = 0.f; sy = 0; }
+        if (sy >= sh - 1) { ay = 0.f; sy = sh - 1; }
+        const int sx1 = min(sx + 1, sw - 1), sy1 = min(sy + 1, sh - 1);
+        const float* m = masks + (size_t)k * size * size;
+        const float* row0 = m + (size_t)(cy1 + sy) * size + cx1;
+        const float* row1 = m + (size_t)(cy1 + sy1) * size + cx1;
+        const float bx = __fsub_rn(1.f, ax), by = __fsub_rn(1.f, ay);
+        const float h0 = __fadd_rn(__fmul_rn(row0[sx], bx), __fmul_rn(row0[sx1], ax));
+        const float h1 = __fadd_rn(__fmul_rn(row1[sx], bx), __fmul_rn(row1[sx1], ax));
+        const float v = __fadd_rn(__fmul_rn(h0, by), __fmul_rn(h1, ay));
+        bit = v > 0.5f ? 1 : 0;
+      }
+      if (full) full[(size_t)k * total + i] = bit;
+      if (bit) mcls = (unsigned char)(classids[k] + 1);
+    }
+    merged[i] = mcls;
+  }
+}
+
+
 }  // namespace
 
 extern "C" size_t disyolo_detect_workspace(int B, int S, int num_class) {
@@ -377,6 +423,20 @@ extern "C" int disyolo_psroi_assemble(const float* score, const float* detection
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(psroi_assemble_kernel, dim3(gx, max_det, B), dim3(256), 0, (hipStream_t)stream, score, detections,
                      B, max_det, map_size, masks, keep);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+extern "C" int disyolo_mask_paste(const float* masks, int n, int size, const int32_t* rects, const int32_t* classids,
+                                  int image_h, int image_w, uint8_t* full_masks, uint8_t* merged, void* stream) {
+  DY_REQUIRE(merged && image_h > 0 && image_w > 0 && n >= 0 && size > 0, "mask_paste: bad args");
+  DY_REQUIRE(n == 0 || (masks && rects && classids), "mask_paste: null pointer");
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_mask_paste(masks, n, size, rects, classids, image_h, image_w, full_masks, merged, s); });
+  const int64_t total = (int64_t)image_h * image_w;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(mask_paste_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, masks, n, size, (const int*)rects,
+                     (const int*)classids, image_h, image_w, (unsigned char*)full_masks, (unsigned char*)merged);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }

@@ -85,6 +85,8 @@ _SIGS = {
     "disyolo_psroi_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 3 +
                            [C.c_float] + [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p]),
     "disyolo_psroi_assemble": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 3),
+    "disyolo_mask_paste": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
     "disyolo_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int64] + [C.c_float] * 5 + [C.c_int64, C.c_float,
                                                                                              C.c_void_p]),
     "disyolo_adam_step_dev": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int64] + [C.c_float] * 5 + [C.c_void_p, C.c_float,
@@ -471,6 +473,18 @@ def bn_act_bwd(dy, x, scale, shift, mean, rstd, dx, dgamma, dbeta, rows, C_, ws:
     buf = ws.get(need)
     _check(load().disyolo_bn_act_bwd(_p(dy), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(dx), _p(dgamma),
                                      _p(dbeta), rows, C_, alpha, _p(buf), buf.numel(), _stream()), "bn_act_bwd")
+
+
+def mask_paste(masks, rects, classids, image_h: int, image_w: int, full_masks, merged) -> None:
+    """masks f32 [n,S,S]; rects int32 [n,8]; classids int32 [n]; full_masks uint8 [n,H,W] or None; merged uint8 [H,W]"""
+    n = int(rects.shape[0])
+    if n:
+        _need(masks, torch.float32, "masks")
+        _need(rects, torch.int32, "rects")
+        _need(classids, torch.int32, "classids")
+    _check(load().disyolo_mask_paste(_p(masks) if n else None, n, int(masks.shape[-1]) if n else 1, _p(rects) if n else None,
+                                     _p(classids) if n else None, image_h, image_w, _p(full_masks), _p(merged), _stream()),
+           "mask_paste")
 
 
 def upsample2x_bwd(src, dst, B, Hs, Ws, src_C, c_off, C_, accumulate=False) -> None:

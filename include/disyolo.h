@@ -219,6 +219,18 @@ int disyolo_psroi_loss(const float* score, const uint8_t* true_masks, int G, con
 int disyolo_psroi_assemble(const float* score, const float* detections, int B, int max_det,
                            int map_size, int k, float* masks, int32_t* keep, void* stream);
 
+/* evaluate()'s per-image mask post-processing (calculate_test_map.py:237-262), the caller side
+ * of `evaluation`: for each of the image's n detections the crop [cy1:cy2, cx1:cx2] of its
+ * size x size f32 mask (disyolo_psroi_assemble output) is resized to (y2-y1) x (x2-x1) with
+ * cv2.resize(INTER_LINEAR) semantics, thresholded (> 0.5) and pasted at [y1:y2, x1:x2] of an
+ * image_h x image_w mask.  rects: int32 [n][8] = cy1,cx1,cy2,cx2, y1,x1,y2,x2 (host side:
+ * np.around(box*size) and correct_yolo_boxes, :121-138,244-251); a detection with an empty crop
+ * or destination contributes nothing.  full_masks uint8 [n][image_h][image_w] or NULL; merged
+ * uint8 [image_h][image_w] = class id + 1 of the LAST detection covering the pixel (:258-266). */
+int disyolo_mask_paste(const float* masks, int n, int size, const int32_t* rects,
+                       const int32_t* classids, int image_h, int image_w, uint8_t* full_masks,
+                       uint8_t* merged, void* stream);
+
 /* ---- optimizer (tf.train.AdamOptimizer.minimize, train_yolo3_mask.py:55) ---- */
 /* TF-form Adam on a flat f32 arena; elements [0, n_decay) also receive the gradient of the
  * l2 regulariser (grad += l2*w; yolo/yolo3_net_pos.py:38).  step t >= 1. */

@@ -775,3 +775,95 @@ def synthetic_batch(B: int, S: int, seed: int = 1234, dtype=torch.float32, num_c
         "yolo2": torch.from_numpy(y2).to(dtype),
         "yolo3": torch.from_numpy(y3).to(dtype),
     }
+
+
+# ---------------------------------------------------------------------------------------------
+# evaluate(): host post-processing of sess.run(net.evaluation) -- SURVEY.md 8(f3)
+# ---------------------------------------------------------------------------------------------
+def correct_yolo_boxes(x1, y1, x2, y2, image_h: int, image_w: int, net_h: int, net_w: int):
+    """calculate_test_map.py:121-138: undo the letter box, normalised box -> integer pixel corners
+    of the original image (np.around = half-to-even, clamped to the image).  Pinned by
+    tests/golden/correct_yolo_boxes.json (the reference's own function executed on the four
+    sample image sizes)."""
+    if (float(net_w) / image_w) < (float(net_h) / image_h):
+        new_w = net_w
+        new_h = (image_h * net_w) // image_w
+    else:
+        new_h = net_h
+        new_w = (image_w * net_h) // image_h
+    x_offset, x_scale = float((net_w - new_w) // 2) / net_w, float(new_w) / net_w
+    y_offset, y_scale = float((net_h - new_h) // 2) / net_h, float(new_h) / net_h
+
+    def corner(v, off, scale, n):
+        return max(min(int(np.around((v - off) / scale * n).astype(np.int32)), n), 0)
+    return (corner(np.float32(x1), x_offset, x_scale, image_w), corner(np.float32(y1), y_offset, y_scale, image_h),
+            corner(np.float32(x2), x_offset, x_scale, image_w), corner(np.float32(y2), y_offset, y_scale, image_h))
+
+
+def letterbox_window(image_h: int, image_w: int, size: int) -> np.ndarray:
+    """the clip window of image_read (calculate_test_map.py:151-169): [top, left, bottom, right] of the
+    resized image inside the size x size letter box, normalised"""
+    imgh, imgw = image_h, image_w
+    if (float(size) / imgw) < (float(size) / imgh):
+        imgh = (imgh * size) // imgw
+        imgw = size
+    else:
+        imgw = (imgw * size) // imgh
+        imgh = size
+    top, left = (size - imgh) // 2, (size - imgw) // 2
+    return np.array([top / size, left / size, (imgh + top) / size, (imgw + left) / size], np.float32)
+
+
+def resize_linear(src: np.ndarray, dst_w: int, dst_h: int) -> np.ndarray:
+    """cv2.resize(src, (dst_w, dst_h), interpolation=cv2.INTER_LINEAR) for a float32 2-D array, restated
+    from OpenCV's documented behaviour (cv2 itself is not installed here: unpinned): pixel centres
+    aligned (src = (dst + 0.5) * scale - 0.5), the source index clamped at both borders with weight
+    0 on the out-of-range neighbour, horizontal pass then vertical pass, all in float32."""
+    src = np.asarray(src, np.float32)
+    sh, sw = src.shape
+
+    def taps(dn, sn):
+        scale = np.float64(sn) / dn
+        f = ((np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        s0 = np.floor(f).astype(np.int64)
+        a = (f - s0.astype(np.float32)).astype(np.float32)
+        lo = s0 < 0
+        a[lo], s0[lo] = 0.0, 0
+        hi = s0 >= sn - 1
+        a[hi], s0[hi] = 0.0, sn - 1
+        return s0, np.minimum(s0 + 1, sn - 1), a
+    x0, x1, ax = taps(dst_w, sw)
+    y0, y1, ay = taps(dst_h, sh)
+    one = np.float32(1.0)
+    rows = src[:, x0] * (one - ax)[None, :] + src[:, x1] * ax[None, :]
+    return (rows[y0, :] * (one - ay)[:, None] + rows[y1, :] * ay[:, None]).astype(np.float32)
+
+
+def paste_detections(det_box: np.ndarray, det_mask, image_h: int, image_w: int, net_size: int):
+    """the per-image body of evaluate (calculate_test_map.py:220-269): every detection's mask is cut
+    out of the size x size map at its rounded box, resized to the un-letterboxed box, thresholded at
+    0.5 and pasted into an image-sized boolean mask; `merged` gets classid+1 where a mask is set,
+    later detections overwriting earlier ones.  Returns (entries, merged): entries = list of dicts
+    {index, classid, score, mask}.  A detection whose crop is empty is skipped (the reference would
+    raise inside cv2.resize there)."""
+    merged = np.zeros((image_h, image_w), np.uint8)
+    entries = []
+    if np.isscalar(det_mask) or np.sum(det_mask) == 0.0:
+        return entries, merged
+    for k in range(det_box.shape[0]):
+        y1n, x1n, y2n, x2n = (np.float32(v) for v in det_box[k, :4])
+        x1, y1, x2, y2 = correct_yolo_boxes(x1n, y1n, x2n, y2n, image_h, image_w, net_size, net_size)
+        if (y2 - y1) * (x2 - x1) <= 0:
+            continue
+        size = det_mask[k].shape[0]
+        cy1, cx1, cy2, cx2 = (int(np.around(v * size).astype(np.int32)) for v in (y1n, x1n, y2n, x2n))
+        crop = np.asarray(det_mask[k], np.float32)[cy1:cy2, cx1:cx2]
+        if crop.size == 0:
+            continue
+        m = resize_linear(crop, x2 - x1, y2 - y1) > 0.5
+        full = np.zeros((image_h, image_w), bool)
+        full[y1:y2, x1:x2] = m
+        cid = int(det_box[k, 4])
+        entries.append({"index": k, "classid": cid, "score": float(det_box[k, 5]), "mask": full})
+        merged[full] = cid + 1
+    return entries, merged

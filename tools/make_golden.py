@@ -89,8 +89,41 @@ def voc_fixture():
                    "overlaps": {"m1": m1.tolist(), "m2": m2.tolist(), "iou": ov.tolist()}}, f)
 
 
+def boxes_fixture():
+    """calculate_test_map.py cannot be imported (tensorflow, cv2 at module level), but its box
+    un-letterboxing method `correct_yolo_boxes` (:121-138) is plain numpy arithmetic: the
+    function is taken out of the reference's own file with `ast` and executed here, in this
+    container only, to produce input/output vectors for the four sample image sizes."""
+    import ast
+    src = open(os.path.join(REF, "calculate_test_map.py")).read()
+    fn = None
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.FunctionDef) and node.name == "correct_yolo_boxes":
+            fn = node
+    mod = ast.Module(body=[fn], type_ignores=[])
+    ns = {"np": np}
+    exec(compile(mod, "calculate_test_map.py", "exec"), ns)
+    ref = ns["correct_yolo_boxes"]
+    from PIL import Image
+    import glob
+    sizes = sorted({Image.open(f).size[::-1] for f in glob.glob(os.path.join(REF, "data/train_sample/images/*.jpg"))})
+    rng = np.random.RandomState(3)
+    cases = []
+    for (h, w) in sizes:
+        for net in (576, 832):
+            boxes = rng.rand(24, 4).astype(np.float32)
+            boxes[:4] = [[0, 0, 1, 1], [0.5, 0.5, 0.5, 0.5], [0.25, 0.1, 0.2, 0.9], [0.999, 0.001, 1.0, 0.0]]
+            for (x1, y1, x2, y2) in boxes:
+                r = ref(None, np.float32(x1), np.float32(y1), np.float32(x2), np.float32(y2), h, w, net, net)
+                cases.append({"box": [float(x1), float(y1), float(x2), float(y2)], "image_hw": [int(h), int(w)],
+                              "net": net, "out": [int(v) for v in r]})
+    with open(os.path.join(OUT, "correct_yolo_boxes.json"), "w") as f:
+        json.dump({"source": "calculate_test_map.py:121-138 executed by tools/make_golden.py", "cases": cases}, f)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     config_fixture()
     voc_fixture()
+    boxes_fixture()
     print("golden fixtures written to", OUT)
