@@ -541,10 +541,11 @@ class YOLONet(object):
                  for i in (75, 67, 59)]
         return preds, self.detections, self.by_idx[82].act
 
-    def evaluation(self, images, clip_window, det_thresh=cfg.OBJ_THRESHOLD):
+    def evaluation(self, images, clip_window, det_thresh=cfg.OBJ_THRESHOLD, masks_on_device: bool = False):
         """``sess.run(net.evaluation)`` (val_test, yolo/yolo3_net_pos.py:862-938): returns
         [det_box, det_mask]: per image an [n,6] array and an [n,S/2,S/2] array (scalar 0.0
-        when the image has no valid detection, :933)."""
+        when the image has no valid detection, :933).  ``masks_on_device``: det_mask entries stay
+        CUDA tensors (10 MB per image at 30 detections -- what postprocess.paste_detections takes)."""
         self.forward(images, clip_window, det_thresh, is_training=False)
         Sm = self.S // 2
         if self.masks is None:
@@ -557,7 +558,8 @@ class YOLONet(object):
         for b in range(self.B):
             det_box.append(det[b][keep[b]])
             if keep[b].any():
-                det_mask.append(self.masks[b][torch.from_numpy(keep[b]).to(self.device)].cpu().numpy())
+                m = self.masks[b][torch.from_numpy(keep[b]).to(self.device)]
+                det_mask.append(m if masks_on_device else m.cpu().numpy())
             else:
                 det_mask.append(np.float32(0.0))
         return [det_box, det_mask]

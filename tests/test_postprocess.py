@@ -63,3 +63,29 @@ def test_mask_paste_matches_oracle(dev):
     # an image without detections: the scalar 0.0 of `evaluation`
     entries, merged = P.paste_detections(np.zeros((0, 6), np.float32), 0.0, 50, 60, net)
     assert entries == [] and int(merged.sum()) == 0
+
+
+@pytest.mark.gpu
+def test_evaluation_to_pasted_masks_end_to_end(dev):
+    """evaluation(masks_on_device=True) -> paste_detections == the oracle's loop on the same
+    evaluation output (a 64x64 net, boosted heads so that there are detections)."""
+    from disyolo_amd.net import YOLONet
+    net = YOLONet(training=False, device=dev, image_size=64, batch_size=2, stage=1, seed=3)
+    with torch.no_grad():
+        for i in (59, 67, 75, 82):
+            net.params["yolo/convolutional%d/weights" % i].mul_(40.0)
+    net.refresh_weights()
+    b = O.synthetic_batch(2, 64, seed=9)
+    h, w = 90, 120
+    win = np.tile(O.letterbox_window(h, w, 64)[None], (2, 1))
+    det_box, det_mask = net.evaluation(b["images"], win, 0.05, masks_on_device=True)
+    torch.cuda.synchronize()
+    assert sum(len(d) for d in det_box) > 0
+    for i in range(2):
+        entries, merged = P.paste_detections(det_box[i], det_mask[i], h, w, 64)
+        host_mask = det_mask[i].cpu().numpy() if torch.is_tensor(det_mask[i]) else det_mask[i]
+        want_entries, want_merged = O.paste_detections(det_box[i], host_mask, h, w, 64)
+        assert [e["index"] for e in entries] == [e["index"] for e in want_entries]
+        for e, we in zip(entries, want_entries):
+            np.testing.assert_array_equal(e["mask"].cpu().numpy(), we["mask"])
+        np.testing.assert_array_equal(merged.cpu().numpy(), want_merged)
