@@ -344,6 +344,21 @@ __global__ __launch_bounds__(256) void mask_paste_kernel(const float* masks, int
 }
 
 
+// 4x4 pixel confusion counts of two uint8 class maps (calculate_test_map.py:303-331): per-block LDS
+// histogram, integer atomics into the caller's int64[16] accumulator (exact, order-independent)
+__global__ __launch_bounds__(256) void confusion16_kernel(const unsigned char* t, const unsigned char* p, int64_t n,
+                                                          unsigned long long* conf) {
+  __shared__ unsigned int h[16];
+  if (threadIdx.x < 16) h[threadIdx.x] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned a = t[i], b = p[i];
+    if (a < 4 && b < 4) atomicAdd(&h[a * 4 + b], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 16 && h[threadIdx.x]) atomicAdd(&conf[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
 }  // namespace
 
 extern "C" size_t disyolo_detect_workspace(int B, int S, int num_class) {
@@ -437,6 +452,18 @@ extern "C" int disyolo_mask_paste(const float* masks, int n, int size, const int
   if (grid > 256 * 16) grid = 256 * 16;
   hipLaunchKernelGGL(mask_paste_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, masks, n, size, (const int*)rects,
                      (const int*)classids, image_h, image_w, (unsigned char*)full_masks, (unsigned char*)merged);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+extern "C" int disyolo_confusion16(const uint8_t* true_map, const uint8_t* pred_map, int64_t n, int64_t* conf,
+                                   void* stream) {
+  DY_REQUIRE(true_map && pred_map && conf && n > 0, "confusion16: bad args");
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_confusion16(true_map, pred_map, n, conf, s); });
+  int grid = (int)((n + 255) / 256);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(confusion16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, true_map, pred_map, n,
+                     (unsigned long long*)conf);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }

@@ -87,6 +87,7 @@ _SIGS = {
     "disyolo_psroi_assemble": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 3),
     "disyolo_mask_paste": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
+    "disyolo_confusion16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "disyolo_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int64] + [C.c_float] * 5 + [C.c_int64, C.c_float,
                                                                                              C.c_void_p]),
     "disyolo_adam_step_dev": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int64] + [C.c_float] * 5 + [C.c_void_p, C.c_float,
@@ -485,6 +486,16 @@ def mask_paste(masks, rects, classids, image_h: int, image_w: int, full_masks, m
     _check(load().disyolo_mask_paste(_p(masks) if n else None, n, int(masks.shape[-1]) if n else 1, _p(rects) if n else None,
                                      _p(classids) if n else None, image_h, image_w, _p(full_masks), _p(merged), _stream()),
            "mask_paste")
+
+
+def confusion16(true_map, pred_map, conf) -> None:
+    """adds the 4x4 confusion counts of two uint8 CUDA class maps to conf (int64 [16], CUDA)"""
+    _need(true_map, torch.uint8, "true_map")
+    _need(pred_map, torch.uint8, "pred_map")
+    _need(conf, torch.int64, "conf")
+    if true_map.numel() != pred_map.numel() or conf.numel() != 16:
+        raise DisyoloError("confusion16: shape mismatch")
+    _check(load().disyolo_confusion16(_p(true_map), _p(pred_map), true_map.numel(), _p(conf), _stream()), "confusion16")
 
 
 def upsample2x_bwd(src, dst, B, Hs, Ws, src_C, c_off, C_, accumulate=False) -> None:

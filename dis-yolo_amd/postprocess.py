@@ -73,3 +73,24 @@ def paste_detections(det_box, det_mask, image_h: int, image_w: int, net_size: in
             entries.append({"index": k, "classid": int(box[k, 4]), "score": float(box[k, 5]),
                             "mask": full[k].bool() if want_full else None})
     return entries, merged
+
+
+class SegmentationAccuracy:
+    """the mIoU block of ``evaluate`` (calculate_test_map.py:303-346): accumulate the pixel confusion
+    counts of (ground-truth class map, merged detection map) pairs on the GPU, image by image."""
+
+    def __init__(self, device):
+        self.conf = torch.zeros(16, dtype=torch.int64, device=device)
+
+    def add(self, true_map, pred_map: torch.Tensor) -> None:
+        t = torch.as_tensor(true_map).to(self.conf.device, torch.uint8).contiguous()
+        p = pred_map.to(self.conf.device, torch.uint8).contiguous()
+        if t.shape != p.shape:
+            raise ValueError("class maps differ in shape: %s vs %s" % (tuple(t.shape), tuple(p.shape)))
+        L.confusion16(t, p, self.conf)
+
+    def result(self) -> List[float]:
+        """[bg_iou, crack_iou, spall_iou, rebar_iou, miou]"""
+        c = self.conf.cpu().numpy().reshape(4, 4).astype(np.float64)
+        ious = [c[k, k] / (c[k, :].sum() + c[:, k].sum() - c[k, k]) for k in range(4)]
+        return ious + [float(np.mean(ious))]

@@ -230,6 +230,12 @@ int disyolo_psroi_assemble(const float* score, const float* detections, int B, i
 int disyolo_mask_paste(const float* masks, int n, int size, const int32_t* rects,
                        const int32_t* classids, int image_h, int image_w, uint8_t* full_masks,
                        uint8_t* merged, void* stream);
+/* semantic-segmentation accuracy of evaluate (calculate_test_map.py:303-346): adds the 4x4 pixel
+ * confusion counts of two uint8 class maps (0 = background, 1..3 = classes; other values are
+ * ignored) to conf int64 [16], conf[true*4 + pred]; the caller zeroes conf before the first image
+ * and forms IoU_c = n_cc / (row_c + column_c - n_cc) at the end. */
+int disyolo_confusion16(const uint8_t* true_map, const uint8_t* pred_map, int64_t n, int64_t* conf,
+                        void* stream);
 
 /* ---- optimizer (tf.train.AdamOptimizer.minimize, train_yolo3_mask.py:55) ---- */
 /* TF-form Adam on a flat f32 arena; elements [0, n_decay) also receive the gradient of the

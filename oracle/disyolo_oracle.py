@@ -867,3 +867,18 @@ def paste_detections(det_box: np.ndarray, det_mask, image_h: int, image_w: int, 
         entries.append({"index": k, "classid": cid, "score": float(det_box[k, 5]), "mask": full})
         merged[full] = cid + 1
     return entries, merged
+
+
+def segmentation_miou(true_maps, pred_maps):
+    """calculate_test_map.py:303-346: pixel confusion counts of the merged class maps (0 = background,
+    1..3 = crack / spall / rebar) over all images; IoU_c = n_cc / (row_c + column_c - n_cc); returns
+    [bg, crack, spall, rebar, mean].  Pinned by tests/golden/miou.json."""
+    conf = np.zeros((4, 4), np.int64)            # [true class][predicted class]
+    for t, p in zip(true_maps, pred_maps):
+        t, p = np.asarray(t), np.asarray(p)
+        assert t.shape == p.shape
+        for a in range(4):
+            for b in range(4):
+                conf[a, b] += int(np.sum((t == a) * (p == b)))
+    ious = [conf[c, c] / (conf[c, :].sum() + conf[:, c].sum() - conf[c, c]) for c in range(4)]
+    return ious + [float(np.mean(ious))]

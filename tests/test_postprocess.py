@@ -12,6 +12,30 @@ import disyolo_oracle as O
 from disyolo_amd import postprocess as P
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "correct_yolo_boxes.json")
+GOLD_MIOU = os.path.join(os.path.dirname(__file__), "golden", "miou.json")
+
+
+def test_segmentation_miou_matches_reference_golden():
+    for c in json.load(open(GOLD_MIOU))["cases"]:
+        got = O.segmentation_miou([np.array(c["true"][n]) for n in c["names"]], [np.array(c["pred"][n]) for n in c["names"]])
+        np.testing.assert_allclose(got, c["mask_acc"], rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_gpu_confusion_counts_match_reference_golden(dev):
+    for c in json.load(open(GOLD_MIOU))["cases"]:
+        acc = P.SegmentationAccuracy(dev)
+        for n in c["names"]:
+            acc.add(np.array(c["true"][n], np.uint8), torch.tensor(c["pred"][n], dtype=torch.uint8, device=dev))
+        np.testing.assert_allclose(acc.result(), c["mask_acc"], rtol=1e-12)
+    # a full-size pair: counts are exact integers whatever the block scheduling
+    g = torch.Generator(device=dev).manual_seed(0)
+    t = torch.randint(0, 4, (754, 1008), device=dev, generator=g, dtype=torch.uint8)
+    p = torch.randint(0, 4, (754, 1008), device=dev, generator=g, dtype=torch.uint8)
+    acc = P.SegmentationAccuracy(dev)
+    acc.add(t, p)
+    want = torch.bincount(t.flatten().long() * 4 + p.flatten().long(), minlength=16)
+    assert torch.equal(acc.conf, want)
 
 
 def test_correct_yolo_boxes_matches_reference_golden():

@@ -121,9 +121,36 @@ def boxes_fixture():
         json.dump({"source": "calculate_test_map.py:121-138 executed by tools/make_golden.py", "cases": cases}, f)
 
 
+def miou_fixture():
+    """the semantic-segmentation accuracy block of `evaluate` (calculate_test_map.py:303-346) is
+    plain numpy on two dicts of class maps: its statements are taken out of the reference's file
+    with `ast` and executed here on random class maps."""
+    import ast
+    src = open(os.path.join(REF, "calculate_test_map.py")).read()
+    fn = [n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "evaluate"][0]
+    body = [s for s in fn.body if 303 <= s.lineno <= 346]
+    code = compile(ast.Module(body=body, type_ignores=[]), "calculate_test_map.py", "exec")
+    rng = np.random.RandomState(11)
+    cases = []
+    for case in range(5):
+        names = ["im%d" % i for i in range(rng.randint(1, 4))]
+        true, pred = {}, {}
+        for n in names:
+            h, w = rng.randint(5, 12), rng.randint(5, 12)
+            true[n] = rng.randint(0, 4, size=(h, w)).astype(np.uint8)
+            pred[n] = np.where(rng.rand(h, w) < 0.6, true[n], rng.randint(0, 4, size=(h, w))).astype(np.uint8)
+        ns = {"np": np, "val_index": names, "val_mergemask": true, "det_masks": pred}
+        exec(code, ns)
+        cases.append({"names": names, "true": {n: true[n].tolist() for n in names},
+                      "pred": {n: pred[n].tolist() for n in names}, "mask_acc": [float(v) for v in ns["mask_acc"]]})
+    with open(os.path.join(OUT, "miou.json"), "w") as f:
+        json.dump({"source": "calculate_test_map.py:303-346 executed by tools/make_golden.py", "cases": cases}, f)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     config_fixture()
     voc_fixture()
     boxes_fixture()
+    miou_fixture()
     print("golden fixtures written to", OUT)
