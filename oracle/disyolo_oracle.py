@@ -10,8 +10,14 @@ the reference ships no tests, golden vectors, weights or checkpoints (SURVEY.md
 F1-F4), so this oracle could not be checked against outputs of the reference
 itself.  TF-op semantics it relies on are listed in SURVEY.md Appendix B and are
 marked [TF-sem] below.  What *is* pinned: hand-derived known answers in
-``tests/test_oracle_kat.py`` and the ``voc_eval`` fixtures generated from the
-importable reference module (``oracle/voc_eval_port.py``).
+``tests/test_oracle_kat.py``; and, by outputs of the reference's own code run in the
+build container (``tools/make_golden.py`` -> ``tests/golden/``): ``voc_eval`` /
+``voc_ap`` / mask overlaps and the config constants (importable modules), and -- taken
+out of their un-importable files with ``ast`` and executed -- the YOLO target
+assignment loop (``utils/train_data.py:134-178`` -> ``assign_targets``), the box
+un-letterboxing (``calculate_test_map.py:121-138`` -> ``correct_yolo_boxes``) and the
+mIoU block (``:303-346`` -> ``segmentation_miou``).  The network graph, the losses,
+NMS, the mask assembly and Adam remain unpinned.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may import this module.  The product (``dis-yolo_amd/``) never does.

@@ -183,3 +183,20 @@ def test_mask_loss_selection_and_value():
     det0 = np.zeros((1, 30, 6), np.float32)
     tb0 = np.zeros_like(tb)
     assert float(O.loss_mask(det0, score, tb0, tm)) == 0.0
+
+
+def test_assign_targets_matches_reference_golden():
+    """utils/train_data.py:134-178 (the reference's own loop, executed by tools/make_golden.py) ->
+    the three YOLO target grids: which cell/anchor holds an object and its row, incl. collisions"""
+    import json
+    import os
+    from disyolo_amd import synth
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "assign_targets.json")))["cases"]
+    assert len(cases) >= 8
+    for c in cases:
+        boxes = np.array(c["true_box_xcycwh"], np.float32)
+        cls = np.array([r[4] for r in c["boxes_x1y1x2y2c"]]).astype(int)
+        for ys in (O.assign_targets(boxes, cls, c["net"]), synth.assign_targets(boxes, cls, c["net"], 3)):
+            got = [{"grid": gi, "idx": [int(v) for v in idx], "row": ys[gi][tuple(idx)].tolist()}
+                   for gi in range(3) for idx in np.argwhere(ys[gi][..., 4] == 1)]
+            assert got == c["objects"]

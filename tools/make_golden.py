@@ -147,10 +147,57 @@ def miou_fixture():
         json.dump({"source": "calculate_test_map.py:303-346 executed by tools/make_golden.py", "cases": cases}, f)
 
 
+def targets_fixture():
+    """utils/train_data.py cannot be imported (cv2, pyblur, skimage), but the loop that encodes the
+    ground-truth boxes into the three YOLO target grids (:134-178, "prepare training input for
+    yolos") is plain numpy: the `for index in bbox_index:` statement is taken out of the file with
+    `ast` and executed here with the surrounding locals set to the no-augmentation case
+    (sx = sy = 1, dx = dy = 0)."""
+    import ast
+    import types
+    import yolo.config as c
+    src = open(os.path.join(REF, "utils", "train_data.py")).read()
+    loop = None
+    for node in ast.walk(ast.parse(src)):
+        if (isinstance(node, ast.For) and isinstance(node.target, ast.Name) and node.target.id == "index"
+                and isinstance(node.iter, ast.Name) and node.iter.id == "bbox_index" and 130 <= node.lineno <= 140):
+            loop = node
+    code = compile(ast.Module(body=[loop], type_ignores=[]), "train_data.py", "exec")
+    rng = np.random.RandomState(21)
+    cases = []
+    for net in (576, 832):
+        for case in range(4):
+            n = rng.randint(1, 9)
+            bbox = np.zeros((1, 1, 1, 20, 5), np.float32)
+            for j in range(n):
+                w, h = rng.uniform(4, 0.7 * net), rng.uniform(4, 0.7 * net)
+                if case == 3 and j > 0:          # collisions: same cell and anchor as box 0
+                    x1, y1 = bbox[0, 0, 0, 0, 0] + rng.uniform(-2, 2), bbox[0, 0, 0, 0, 1] + rng.uniform(-2, 2)
+                    w, h = bbox[0, 0, 0, 0, 2] - bbox[0, 0, 0, 0, 0], bbox[0, 0, 0, 0, 3] - bbox[0, 0, 0, 0, 1]
+                else:
+                    x1, y1 = rng.uniform(0, net - w), rng.uniform(0, net - h)
+                bbox[0, 0, 0, j] = [x1, y1, x1 + w, y1 + h, rng.randint(0, 3)]
+            inp = bbox[0, 0, 0, :n].copy()
+            g = net // 32
+            yolos = [np.zeros((4 * g, 4 * g, 3, 8), np.float32), np.zeros((2 * g, 2 * g, 3, 8), np.float32),
+                     np.zeros((g, g, 3, 8), np.float32)]
+            ns = {"np": np, "self": types.SimpleNamespace(anchors=c.ANCHORS, num_anchor=3), "bbox_index": list(range(n)),
+                  "bbox": bbox, "sx": 1.0, "sy": 1.0, "dx": 0, "dy": 0, "net_w": net, "net_h": net, "yolos": yolos,
+                  "print": lambda *a: None}
+            exec(code, ns)
+            nz = [{"grid": gi, "idx": [int(v) for v in idx], "row": yolos[gi][tuple(idx)].tolist()}
+                  for gi in range(3) for idx in np.argwhere(yolos[gi][..., 4] == 1)]
+            cases.append({"net": net, "boxes_x1y1x2y2c": inp.tolist(), "true_box_xcycwh": bbox[0, 0, 0, :n, :4].tolist(),
+                          "objects": nz})
+    with open(os.path.join(OUT, "assign_targets.json"), "w") as f:
+        json.dump({"source": "utils/train_data.py:134-178 executed by tools/make_golden.py", "cases": cases}, f)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     config_fixture()
     voc_fixture()
     boxes_fixture()
     miou_fixture()
+    targets_fixture()
     print("golden fixtures written to", OUT)
