@@ -60,3 +60,27 @@ def test_bucket_plan_covers_arena_in_backward_order():
     triggers = [t for t, _, _ in b]
     assert triggers == sorted(triggers, reverse=True)
     assert plan_buckets(spans, 10 ** 9) == [(53, 0, 2030)]
+
+
+def test_committed_bench_line_follows_the_contract():
+    """the JSON line bench.py printed for the committed profile run carries every field the driver
+    and the judge read (metric/unit/value..., roofline, cpu_baseline, config.workload)"""
+    import json
+    import os
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01h_bench_stage1.json")
+    d = json.loads(open(p).read())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "images/sec" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and d["dtype"] == "bf16" and "workload" in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference")
+    # value is consistent with the step time: images per step / seconds per step
+    assert abs(d["value"] - d["config"]["global_batch"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
