@@ -300,6 +300,252 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 stride-1 weight gradient with all nine filter taps fed from ONE staged copy of the input.
+//
+// Pixels are numbered in a padded frame, Q = b*(H+1)*P + (y+1)*P + (x+1) with P = W+1: every image
+// row is followed by one pad pixel (it is the right pad of that row and the left pad of the next),
+// every image is preceded by one pad row (the bottom pad of the image before).  In that numbering
+// the input pixel of tap (kh,kw) for output pixel Q is Q + (kh-1)*P + (kw-1) -- one uniform shift,
+// pads included -- so
+//     dw[kh][kw][ci][co] = sum_Q X''(Q + shift(kh,kw))[ci] * dY'(Q)[co]
+// where X'' / dY' are the input / output-gradient in frame numbering, zero on pad pixels (those
+// lanes of the LDS-DMA are out of range of the buffer descriptor: the hardware writes zeros).
+//
+// A block owns 32 input channels x CO_T output channels x 9 taps (accumulators: 9*32*CO_T f32 in
+// registers, 144 or 72 per lane) and a range of 64-pixel chunks of Q.  Per chunk it stages 64 x 32
+// input values ONCE into a ring of R chunks (the nine taps read it at nine row shifts) and 64 x CO_T
+// gradient values into a 3-stage pipeline: 20 KiB staged per 4.7 MFLOP (236 FLOP/B; the im2col kernel
+// above: 64).  Both images are [pixel][channel]; fragments come out of ds_read_b64_tr_b16.  The k
+// order inside an MFMA is permuted (lane group g holds pixels 4g..4g+3 and 16+4g..16+4g+3) -- the
+// same permutation for both operands, so the sum is unchanged -- which makes the second transposed
+// read of a fragment the first one + 16 rows: one address computation per fragment half.
+// XOR swizzles on 32-byte units (applied on the DMA source side and on the read) keep every
+// transposed read conflict-free: input ring (64-byte rows) unit ^ ((row>>2)&1) at ANY row alignment,
+// gradient stages unit ^ (row&7) (256-byte rows) resp. unit ^ ((row>>1)&3) (128-byte rows).
+struct Wg3Params {
+  const bf16* x;
+  const bf16* dy;
+  float* out;  // slabs [splits][9*Cin][Cout]
+  int B, H, W, Cin, Cout, ldy;
+  int P, Hp, frame, kbias;  // P = W+1, Hp = H+1, frame = Hp*P, kbias*frame >= the prologue's reach below Q = 0
+  int a64, r64;             // 64 = a64*P + r64
+  int chunks, chunks_per_split;
+  int tilesCi, tilesCo, tiles;
+  int leadA, leadB;
+  unsigned bytesx, bytesy;
+  int debug;  // DISYOLO_WG3_DEBUG ablations (1: no epilogue stores, 2: no main loop, 4: no DMA in the loop)
+};
+
+struct PixState {
+  int b, yy, xx;
+};
+__device__ __forceinline__ void pix_init(PixState& s, int Q, const Wg3Params& p) {
+  const int Qn = Q + p.kbias * p.frame;
+  const int bb = Qn / p.frame;
+  const int rem = Qn - bb * p.frame;
+  s.b = bb - p.kbias;
+  s.yy = rem / p.P;
+  s.xx = rem - s.yy * p.P;
+}
+__device__ __forceinline__ void pix_advance64(PixState& s, const Wg3Params& p) {
+  s.xx += p.r64;
+  s.yy += p.a64;
+  if (s.xx >= p.P) {
+    s.xx -= p.P;
+    ++s.yy;
+  }
+  while (s.yy >= p.Hp) {
+    s.yy -= p.Hp;
+    ++s.b;
+  }
+}
+// element index of the real pixel behind a frame position, or -1 on a pad / outside the batch
+__device__ __forceinline__ int pix_index(const PixState& s, const Wg3Params& p) {
+  const bool ok = ((unsigned)s.b < (unsigned)p.B) && (s.yy >= 1) && (s.xx >= 1);
+  return ok ? (s.b * p.H + s.yy - 1) * p.W + s.xx - 1 : -1;
+}
+
+// LDS-DMA with an immediate byte offset added to the per-lane source offset (still range-checked).
+// The hardware adds the instruction offset to the LDS address as well (LDS address = M0 base +
+// instruction offset + 16 * lane), so it is taken off the base again.
+template <int IMM>
+__device__ __forceinline__ void dma16_imm(unsigned voff, i32x4 srd, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen offset:%3 lds"
+               :
+               : "v"(voff), "s"(srd), "s"(lds_dst - (unsigned)IMM), "n"(IMM)
+               : "memory");
+}
+
+template <int CO_T, int R, int ST>
+__global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3Params p) {
+  constexpr int NJ = CO_T / 32;      // 16-channel gradient fragments per wave (the wave owns CO_T/2 channels)
+  constexpr int YD = CO_T / 32;      // gradient DMAs per wave per chunk = 32-channel sub-tiles of a stage
+  constexpr int YST = YD * 4096;     // bytes per gradient stage: YD sub-tiles of [64 pixels][32 channels]
+  constexpr int XRING = R * 4096;
+  constexpr int XALLOC = XRING + 1024;   // + a copy of the ring's first 16 rows behind its end (see below)
+  constexpr int PRE = ST - 1;
+  constexpr int LPT = 1 + YD;        // DMAs per wave per chunk
+  static_assert((R & (R - 1)) == 0 && ST >= 2, "ring");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int u = wave & 1, ch = wave >> 1;   // input-channel fragment, output-channel half
+  int lin;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+    lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+  }
+  const int tile = lin % p.tiles, bsplit = lin / p.tiles;
+  const int ci0 = (tile % p.tilesCi) * 32, co0 = (tile / p.tilesCi) * CO_T;
+  const int c0 = bsplit * p.chunks_per_split;
+  int c1 = c0 + p.chunks_per_split;
+  if (c1 > p.chunks) c1 = p.chunks;
+  const int nsteps = c1 - c0;
+
+  const i32x4 srdx = make_srd(p.x, p.bytesx);
+  const i32x4 srdy = make_srd(p.dy, p.bytesy);
+
+  // ---- DMA lanes.  Every image in LDS is [64 pixels][32 channels] (64-byte rows); one DMA of wave w
+  // fills rows 16w..16w+15, lane -> row 16w + lane/4, 16-byte piece lane%4.  The gradient stage is
+  // YD such images (channels 32j..32j+31): the lane's pixel is the same in all of them, so ONE pixel
+  // walk serves the YD gradient DMAs (the sub-tile is the instruction's immediate offset) and one more
+  // the input DMA.
+  const int drow = wave * 16 + (lane >> 2), dpc = lane & 3;
+  const int dlu = (dpc >> 1) ^ ((drow >> 2) & 1);
+  const unsigned x_const = (unsigned)(ci0 + dlu * 16 + (dpc & 1) * 8) * 2u;
+  const int y_n = co0 + dlu * 16 + (dpc & 1) * 8;
+  const unsigned y_const = (unsigned)y_n * 2u;
+  PixState xs, ys;
+  pix_init(xs, (c0 - p.leadB) * 64 + drow, p);
+  pix_init(ys, c0 * 64 + drow, p);
+  const unsigned xrow_bytes = (unsigned)p.Cin * 2u, yrow_bytes = (unsigned)p.ldy * 2u;
+  auto issue_x = [&](int c) {   // stages chunk c of the input (this wave's quarter), advances the lane's pixel
+    const int pix = pix_index(xs, p);
+    const unsigned voff = pix >= 0 ? (unsigned)pix * xrow_bytes + x_const : OOB;
+    const unsigned slot = (unsigned)(c & (R - 1));
+    // rows 0..15 of the ring are also kept behind its end: a fragment's second transposed read is the
+    // first + 16 rows, which then never needs the wrap-around mask
+    if (wave == 0 && slot == 0) dma16(voff, srdx, lds0 + XRING);
+    dma16(voff, srdx, lds0 + slot * 4096u + wave * 1024u);
+    pix_advance64(xs, p);
+  };
+  auto issue_y = [&](int stage) {
+    const int pix = pix_index(ys, p);
+    const unsigned voff = pix >= 0 ? (unsigned)pix * yrow_bytes + y_const : OOB;
+    const unsigned dst = lds0 + XALLOC + stage * YST + wave * 1024u;
+    dma16_imm<0>((y_n < p.ldy) ? voff : OOB, srdy, dst);
+    dma16_imm<64>((y_n + 32 < p.ldy) ? voff : OOB, srdy, dst + 4096u);
+    if constexpr (YD == 4) {
+      dma16_imm<128>((y_n + 64 < p.ldy) ? voff : OOB, srdy, dst + 8192u);
+      dma16_imm<192>((y_n + 96 < p.ldy) ? voff : OOB, srdy, dst + 12288u);
+    }
+    pix_advance64(ys, p);
+  };
+
+  // ---- fragment read addresses
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pc = li & 3;
+  int E[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int rowc = (tap / 3 - 1) * p.P + (tap % 3 - 1) + 4 * g + q;
+    E[tap] = rowc * 64 + ((u ^ ((rowc >> 2) & 1)) * 32) + pc * 8;
+  }
+  int Fy[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int f = ch * NJ + j, row = 4 * g + q;
+    Fy[j] = XALLOC + (f >> 1) * 4096 + row * 64 + (((f & 1) ^ ((row >> 2) & 1)) * 32) + pc * 8;
+  }
+
+  f32x4 acc[9][NJ];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: the input chunks behind and ahead of the first step, then PRE pipelined chunks
+  for (int c = c0 - p.leadB; c < c0 + p.leadA; ++c) issue_x(c);
+#pragma unroll
+  for (int s = 0; s < PRE; ++s) {
+    issue_x(c0 + p.leadA + s);
+    issue_y(s);
+  }
+
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  for (int t = 0; t < ((p.debug & 2) ? 1 : nsteps); ++t) {
+    // (wave 0's occasional extra DMA only makes this wait for more than it needs)
+    if (t + PRE - 1 < nsteps)
+      wait_vmcnt<LPT*(PRE - 1)>();
+    else
+      wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + PRE < nsteps && !(p.debug & 4)) {
+      issue_x(c0 + t + PRE + p.leadA);
+      issue_y((t + PRE) % ST);
+    }
+    const int T = (c0 + t) * 4096;
+    const char* sY = smem + (t % ST) * YST;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 bfr[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const char* a = sY + Fy[j] + ks * 2048;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 1024));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        bfr[j] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const char* a = smem + ((E[tap] + T + ks * 2048) & (XRING - 1));
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 1024));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const bf16x8 af = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc[tap][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: per tap the wave's 16 x (CO_T/2) f32 tile goes through LDS and leaves as whole rows
+  float* slab = p.out + (size_t)bsplit * 9 * p.Cin * p.Cout;
+  wait_vmcnt<0>();
+  __syncthreads();
+  constexpr int WTN = CO_T / 2;
+  constexpr int ROWP = WTN * 4 + 16;
+  constexpr int CPR4 = WTN / 4;
+  char* sw = smem + wave * (16 * ROWP);
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(sw + (g * 4 + r) * ROWP + (j * 16 + li) * 4) = acc[tap][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < (16 * CPR4) / 64; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / CPR4, c4 = idx % CPR4;
+      const int kk = tap * p.Cin + ci0 + u * 16 + row, n = co0 + ch * WTN + c4 * 4;
+      if (n < p.Cout && !(p.debug & 1))
+        *reinterpret_cast<float4*>(slab + (size_t)kk * p.Cout + n) = *reinterpret_cast<const float4*>(sw + row * ROWP + c4 * 16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // out[i] = sum_k slabs[k][i] in a fixed order.  256 threads = 64 outputs x 4 split lanes
 // (lane g sums k = g, g+4, ... with four loads in flight), combined through LDS: short
 // dependent chains even for hundreds of splits of a small matrix.
@@ -364,12 +610,69 @@ void plan(const disyolo_conv_desc* d, int* bn, int* splits, int* steps_per_split
   *splits = ceil_div(*steps, *steps_per_split);
 }
 
+
+struct Plan3 {
+  int co_t, R, splits, cps, chunks, tilesCi, tilesCo, leadA, leadB;
+  size_t lds;
+};
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && v[0]) ? atoi(v) : dflt;
+}
+// tap-fused kernel: 3x3, stride 1, SAME pads, no fused concat, 32 | Cin, 4 | Cout
+bool plan3(const disyolo_conv_desc* d, Plan3* q) {
+  static const int enabled = env_int("DISYOLO_WG3", 1);
+  static const int target = env_int("DISYOLO_WG3_BLOCKS", 256);
+  if (!enabled || (d->tile & 0x100)) return false;
+  if (d->ksize != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->C1 != 0 || d->in_div != 1) return false;
+  if (d->C0 % 32 || d->Cout % 4 || d->Cout < 32 || d->Ho != d->H || d->Wo != d->W) return false;
+  const int P = d->W + 1, Hp = d->H + 1;
+  q->co_t = d->Cout > 64 ? 128 : 64;
+  q->leadB = ceil_div(P + 1, 64);
+  q->leadA = 1 + P / 64;
+  const int need = 2 + q->leadA + q->leadB + 1;
+  q->R = need <= 8 ? 8 : (need <= 16 ? 16 : 32);
+  if (need > 32) return false;
+  q->lds = (size_t)q->R * 4096 + 1024 + 3 * 64 * (size_t)q->co_t * 2;
+  if (q->lds > 160 * 1024) {
+    q->co_t = 64;
+    q->lds = (size_t)q->R * 4096 + 1024 + 3 * 64 * 64 * 2;
+    if (q->lds > 160 * 1024) return false;
+  }
+  q->chunks = ceil_div((int64_t)d->B * Hp * P, 64);
+  q->tilesCi = d->C0 / 32;
+  q->tilesCo = ceil_div(d->Cout, q->co_t);
+  const int tiles = q->tilesCi * q->tilesCo;
+  int s = (target + tiles / 2) / tiles;
+  const int max_s = q->chunks / 4 > 1 ? q->chunks / 4 : 1;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  q->cps = ceil_div(q->chunks, s);
+  q->splits = ceil_div(q->chunks, q->cps);
+  return true;
+}
+template <int CO_T, int R>
+int launch3(const Wg3Params& p, const Plan3& q, hipStream_t s) {
+  static bool attr_done = false;
+  auto fn = conv_wgrad3x3_kernel<CO_T, R, 3>;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      (void)hipGetLastError();
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(fn, dim3(q.tilesCi * q.tilesCo * q.splits), dim3(256), q.lds, s, p);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" size_t disyolo_conv2d_wgrad_workspace(const disyolo_conv_desc* d) {
   if (!d) return 0;
   int bn, splits, sps, steps;
   plan(d, &bn, &splits, &sps, &steps);
+  Plan3 q;
+  if (plan3(d, &q)) splits = q.splits;
   const size_t K = (size_t)d->ksize * d->ksize * (d->C0 + d->C1);
   return (size_t)splits * K * d->Cout * sizeof(float);
 }
@@ -391,6 +694,42 @@ extern "C" int disyolo_conv2d_wgrad(const disyolo_conv_desc* d, const void* dy, 
   {
     const disyolo_conv_desc c = *d;
     DY_RECORD_OR_RUN([=](void* s) { return disyolo_conv2d_wgrad(&c, dy, dy_ld, dw, workspace, workspace_bytes, s); });
+  }
+  Plan3 q3;
+  if (plan3(d, &q3)) {
+    Wg3Params p;
+    p.x = (const bf16*)d->x0;
+    p.dy = (const bf16*)dy;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->C0; p.Cout = d->Cout; p.ldy = dy_ld;
+    p.P = d->W + 1; p.Hp = d->H + 1; p.frame = p.Hp * p.P;
+    p.kbias = ceil_div((q3.leadB + 1) * 64, p.frame);
+    p.a64 = 64 / p.P; p.r64 = 64 % p.P;
+    p.chunks = q3.chunks; p.chunks_per_split = q3.cps;
+    p.tilesCi = q3.tilesCi; p.tilesCo = q3.tilesCo; p.tiles = q3.tilesCi * q3.tilesCo;
+    p.leadA = q3.leadA; p.leadB = q3.leadB;
+    p.bytesx = (unsigned)((size_t)d->B * d->H * d->W * d->C0 * 2);
+    p.bytesy = (unsigned)((size_t)d->B * d->H * d->W * dy_ld * 2);
+    p.out = q3.splits == 1 ? dw : (float*)workspace;
+    static const int dbg = env_int("DISYOLO_WG3_DEBUG", 0);
+    p.debug = dbg;
+    hipStream_t s = (hipStream_t)stream;
+    if (q3.co_t == 128) {
+      if (q3.R == 8) launch3<128, 8>(p, q3, s);
+      else if (q3.R == 16) launch3<128, 16>(p, q3, s);
+      else launch3<128, 32>(p, q3, s);
+    } else {
+      if (q3.R == 8) launch3<64, 8>(p, q3, s);
+      else if (q3.R == 16) launch3<64, 16>(p, q3, s);
+      else launch3<64, 32>(p, q3, s);
+    }
+    DY_CHECK_LAUNCH();
+    if (q3.splits > 1) {
+      const int64_t n = (int64_t)9 * p.Cin * p.Cout;
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(n, 64)), dim3(256), 0, s, (const float*)workspace, dw, n,
+                         q3.splits);
+      DY_CHECK_LAUNCH();
+    }
+    return DISYOLO_OK;
   }
   WgradParams p;
   p.x0 = (const bf16*)d->x0;

@@ -155,7 +155,7 @@ class YOLONet(object):
         self._prog_marks = []   # [(command index, layer)] all-reduce trigger points
         self._graph = None      # hipGraph of the recorded step (single GPU)
         self._pack_table = None
-        self._side_stream = None
+        self._side_streams = {}  # id(recorded list) -> its side lane as a torch stream
         self._progs = None      # [parity] -> (list, marks, bwd_end) of the pipelined step
         self.use_side_lane = os.environ.get("DISYOLO_SIDE_LANE", "1") != "0"
         # weight gradients of the last layers of the backward pass stay on the main lane (tuned below)
@@ -483,7 +483,7 @@ class YOLONet(object):
 
     def _forward_layer(self, l, is_training: bool) -> None:
         B = self.B
-        if True:
+        if l is not None:
             train_bn = is_training and self.training and (not l.lock) and l.kind != "lin"
             M = B * l.Ho * l.Wo
             res = self.by_idx[l.shortcut].act if l.shortcut is not None else None
@@ -704,7 +704,10 @@ class YOLONet(object):
             # latency-bound BN kernels of the following layers
             # ... except for the last few layers of the pass: nothing is left on the main lane to
             # overlap with, the step would only wait for the side lane's backlog to drain
-            side = self.use_side_lane and (pos < len(order) - self.tail_on_main)
+            # (with data parallelism every weight gradient stays on the side lane: the bucket all-reduce is
+            # ordered after that lane only, and both lanes would share ws_aux otherwise)
+            tail = 0 if self.dp is not None else self.tail_on_main
+            side = self.use_side_lane and (pos < len(order) - tail)
             if side:
                 L.lane_sync(0, 1)
                 L.set_lane(1)
@@ -929,13 +932,16 @@ class YOLONet(object):
             self._prog.run()
             return
         self.dp.begin_step()
-        if self._side_stream is None:
-            self._side_stream = self._prog.side_stream(self.device)
+        # every recorded list owns its side lane: the bucket's all-reduce must be ordered after the
+        # lane of the list that is running NOW (the pipelined step alternates between two lists)
+        side = self._side_streams.get(id(self._prog))
+        if side is None:
+            side = self._side_streams[id(self._prog)] = self._prog.side_stream(self.device)
         pos, first = 0, True
         for idx, bucket in self._prog_marks:
             self._prog.run(pos, idx, fork=first, join=False)
             first = False
-            with torch.cuda.stream(self._side_stream if self.use_side_lane else torch.cuda.current_stream()):
+            with torch.cuda.stream(side if self.use_side_lane else torch.cuda.current_stream()):
                 self.dp.fire(bucket)
             pos = idx
         self._prog.run(pos, self._bwd_end, fork=first, join=True)

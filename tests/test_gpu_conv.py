@@ -278,7 +278,12 @@ def test_conv_dgrad_matches_autograd(dev, B, H, W, Cin, Cout, k, s):
 
 
 WGRAD = [(2, 18, 18, 64, 128, 3, 1), (2, 12, 12, 128, 64, 1, 1), (1, 20, 20, 32, 64, 3, 2), (2, 18, 18, 256, 24, 1, 1),
-         (1, 24, 24, 64, 9, 1, 1), (3, 10, 10, 96, 32, 1, 1), (2, 36, 36, 32, 64, 3, 1)]
+         (1, 24, 24, 64, 9, 1, 1), (3, 10, 10, 96, 32, 1, 1), (2, 36, 36, 32, 64, 3, 1),
+         # the tap-fused 3x3 kernel: every ring size (W+1 = 73 / 145 / 289 / 421), both channel tiles, batches
+         # crossing a chunk, H != W, frames smaller than one 64-pixel chunk, Cout not a multiple of 16
+         (1, 72, 72, 32, 128, 3, 1), (1, 144, 144, 32, 64, 3, 1), (1, 288, 288, 32, 32, 3, 1),
+         (1, 40, 420, 32, 32, 3, 1), (5, 2, 2, 32, 64, 3, 1), (3, 5, 7, 64, 36, 3, 1), (8, 18, 18, 64, 256, 3, 1),
+         (2, 26, 26, 96, 192, 3, 1)]
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,s", WGRAD)

@@ -27,13 +27,26 @@ def rel_err(got, want):
 
 def make_net(dev, training, stage, B=2, S=64, seed=0):
     net = YOLONet(training=training, device=dev, image_size=S, batch_size=B, stage=stage, seed=seed)
-    # make the heads produce non-trivial logits / detections
+    # make the heads produce non-trivial logits / detections.  The biases come from an explicit,
+    # seeded CPU generator: round 1 drew them from the unseeded global CUDA RNG, so every run tested
+    # different logits and a score / IoU comparison decided by the last ulp of the device's expf could
+    # flip once in many runs (the one unexplained detect failure of round 1)
+    g = torch.Generator().manual_seed(7919 + seed)
     with torch.no_grad():
         for i in (59, 67, 75, 82):
             net.params["yolo/convolutional%d/weights" % i].mul_(6.0)
-            net.params["yolo/convolutional%d/biases" % i].normal_(0, 0.5)
+            b = net.params["yolo/convolutional%d/biases" % i]
+            b.copy_((torch.randn(b.shape, generator=g) * 0.5).to(b.device))
     net.refresh_weights()
     return net
+
+
+def dump_on_mismatch(name, **arrays):
+    """save the inputs and both outputs of a failed comparison where gpurun brings them back"""
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    np.savez_compressed(os.path.join(out, name + ".npz"), **{k: np.asarray(v) for k, v in arrays.items()})
 
 
 def oracle_params(net, dtype=torch.float32):
@@ -68,9 +81,14 @@ def test_detect_matches_oracle_on_same_logits(dev):
     want = O.filter_detections(pred[2], pred[3], pred[5], b["clip_window"], 0.05)
     got = det.cpu().numpy()
     assert (want[:, :, 5] > 0).sum() >= 20, "test needs a non-trivial number of detections"
-    np.testing.assert_array_equal(got[:, :, 4], want[:, :, 4])
-    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
-    assert net.det_count.cpu().tolist() == [(want[i, :, 5] > 0).sum() for i in range(2)]
+    try:
+        np.testing.assert_array_equal(got[:, :, 4], want[:, :, 4])
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+        assert net.det_count.cpu().tolist() == [(want[i, :, 5] > 0).sum() for i in range(2)]
+    except AssertionError:
+        dump_on_mismatch("detect_mismatch", got=got, want=want, count=net.det_count.cpu().numpy(),
+                         clip_window=np.asarray(b["clip_window"]), **{"logits%d" % i: y.numpy() for i, y in enumerate(yolos)})
+        raise
 
 
 def test_evaluation_matches_oracle_val_test(dev):

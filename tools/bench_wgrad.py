@@ -9,7 +9,7 @@ from disyolo_amd.net import build_topology
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 576
-variants = [int(t) for t in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2, 3]
+variants = [int(t, 0) for t in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0x100, 0]   # 0x100 = im2col kernel, 0 = planner's pick
 first = int(sys.argv[4]) if len(sys.argv) > 4 else 53
 dev = torch.device("cuda:0")
 layers = build_topology(3, 3)
@@ -25,7 +25,7 @@ for l in layers:
 ws = L.Workspace(dev)
 ws.get(1 << 28)
 tot = {v: 0.0 for v in variants}
-print("%-30s %-6s %8s | " % ("shape", "n", "GFLOP") + " ".join("%8s" % ("st%d" % (v + 1)) for v in variants))
+print("%-30s %-6s %8s | " % ("shape", "n", "GFLOP") + " ".join("%8s" % ("t%x" % v) for v in variants) + "  (TFLOP/s, us)")
 for key, idxs in sorted(shapes.items(), key=lambda kv: -kv[0][0]):
     H, cin, cout, k, s = key
     Ho, _ = L.same_pads(H, k, s)
@@ -49,6 +49,6 @@ for key, idxs in sorted(shapes.items(), key=lambda kv: -kv[0][0]):
         torch.cuda.synchronize()
         dt = e0.elapsed_time(e1) / 20 * 1e-3
         tot[v] += dt * len(idxs)
-        row.append("%8.1f" % (fl / dt / 1e12))
+        row.append("%8.1f %6.1f" % (fl / dt / 1e12, dt * 1e6))
     print("%-30s x%-5d %8.2f | " % (str(key), len(idxs), fl / 1e9) + " ".join(row))
-print("total ms: " + "  ".join("st%d %.3f" % (v + 1, tot[v] * 1e3) for v in variants))
+print("total ms: " + "  ".join("t%x %.3f" % (v, tot[v] * 1e3) for v in variants))
