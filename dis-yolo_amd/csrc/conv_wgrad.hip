@@ -595,15 +595,21 @@ __global__ __launch_bounds__(1024) void conv_first_wgrad_kernel(const float* img
   slabs[(size_t)blockIdx.x * nout + o] = acc;
 }
 
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && v[0]) ? atoi(v) : dflt;
+}
 void plan(const disyolo_conv_desc* d, int* bn, int* splits, int* steps_per_split, int* steps) {
   const int M = d->B * d->Ho * d->Wo;
   const int K = d->ksize * d->ksize * (d->C0 + d->C1);
   *bn = d->Cout > 64 ? 128 : (d->Cout > 32 ? 64 : 32);
   const int tiles = ceil_div(K, 128) * ceil_div(d->Cout, *bn);
   *steps = ceil_div(M, 32);
-  int s = 512 / tiles;  // fill the 256 CUs about twice; a full grid needs no pixel split
+  static const int target = env_int("DISYOLO_WG_BLOCKS", 256);
+  static const int min_steps = env_int("DISYOLO_WG_MINSTEPS", 16);
+  int s = target / tiles;  // fill the 256 CUs about twice; a full grid needs no pixel split
   if (s < 1) s = 1;
-  const int max_s = ceil_div(*steps, 8);
+  const int max_s = ceil_div(*steps, min_steps);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
   *steps_per_split = ceil_div(*steps, s);
@@ -615,10 +621,6 @@ struct Plan3 {
   int co_t, R, splits, cps, chunks, tilesCi, tilesCo, leadA, leadB;
   size_t lds;
 };
-int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && v[0]) ? atoi(v) : dflt;
-}
 // tap-fused kernel: 3x3, stride 1, SAME pads, no fused concat, 32 | Cin, 4 | Cout
 bool plan3(const disyolo_conv_desc* d, Plan3* q) {
   static const int enabled = env_int("DISYOLO_WG3", 1);

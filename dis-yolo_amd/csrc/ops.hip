@@ -229,6 +229,52 @@ __global__ void bump_counter_kernel(int64_t* counter) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *counter += 1;
 }
 
+// Adam with the learning rate AND the step count in device memory (a recorded step can follow a
+// schedule: the host only rewrites one float), which also produces the value of the l2 term,
+// 0.5*l2*sum(w[0:n_decay]^2) of the PRE-update weights (what tf.losses.get_total_loss() adds,
+// yolo/yolo3_net_pos.py:61), from the sweep over the weights it makes anyway: per-block partial
+// sums (fixed grid, fixed order: deterministic) finished by the trailing counter kernel.
+__global__ __launch_bounds__(256) void adam_fused_kernel(float* w, const float* g, float* m, float* v, int64_t n,
+                                                         int64_t n_decay, const float* lr_dev, float b1, float b2,
+                                                         float eps, float l2, float gscale, const int64_t* counter,
+                                                         float* part) {
+  __shared__ float sh[4];
+  const double t = (double)(*counter + 1);
+  const float lr_t = (float)((double)*lr_dev * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float ss = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float wi = w[i];
+    float gi = g[i] * gscale;
+    if (i < n_decay) {
+      gi += l2 * wi;
+      ss += wi * wi;
+    }
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    w[i] = wi - lr_t * mi / (sqrtf(vi) + eps);
+  }
+  if (part) {
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  }
+}
+__global__ __launch_bounds__(64) void adam_fused_tail_kernel(int64_t* counter, const float* part, int nb, float coef,
+                                                             float* reg_out) {
+  if (part && reg_out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 64) s += (double)part[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) reg_out[0] = (float)(s * coef);
+  }
+  if (threadIdx.x == 0) *counter += 1;
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* w, int64_t n, float* part) {
   __shared__ float sh[4];
   float acc = 0.f;
@@ -368,6 +414,34 @@ extern "C" int disyolo_adam_step_dev(float* w, const float* grad, float* m, floa
                      grad_scale, (const int64_t*)step_counter);
   DY_CHECK_LAUNCH();
   hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(64), 0, s, step_counter);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+extern "C" size_t disyolo_adam_fused_workspace(int64_t n) { return n > 0 ? 4096 * sizeof(float) : 0; }
+
+extern "C" int disyolo_adam_step_fused(float* w, const float* grad, float* m, float* v, int64_t n, int64_t n_decay,
+                                       const float* lr_dev, float beta1, float beta2, float eps, float l2,
+                                       int64_t* step_counter, float grad_scale, float* reg_loss_out, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  DY_REQUIRE(w && grad && m && v && lr_dev && step_counter && n > 0 && n_decay >= 0 && n_decay <= n, "adam_fused: bad args");
+  if (reg_loss_out && (!workspace || workspace_bytes < disyolo_adam_fused_workspace(n))) {
+    disyolo_set_error("adam_fused: workspace too small");
+    return DISYOLO_E_WORKSPACE;
+  }
+  DY_RECORD_OR_RUN([=](void* s) {
+    return disyolo_adam_step_fused(w, grad, m, v, n, n_decay, lr_dev, beta1, beta2, eps, l2, step_counter, grad_scale,
+                                   reg_loss_out, workspace, workspace_bytes, s);
+  });
+  int grid = ceil_div(n, 256);
+  if (grid > 4096) grid = 4096;
+  hipStream_t s = (hipStream_t)stream;
+  float* part = reg_loss_out ? (float*)workspace : nullptr;
+  hipLaunchKernelGGL(adam_fused_kernel, dim3(grid), dim3(256), 0, s, w, grad, m, v, n, n_decay, lr_dev, beta1, beta2, eps,
+                     l2, grad_scale, (const int64_t*)step_counter, part);
+  DY_CHECK_LAUNCH();
+  hipLaunchKernelGGL(adam_fused_tail_kernel, dim3(1), dim3(64), 0, s, step_counter, (const float*)part, grid, 0.5f * l2,
+                     reg_loss_out);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }

@@ -92,6 +92,9 @@ _SIGS = {
                                                                                              C.c_void_p]),
     "disyolo_adam_step_dev": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int64] + [C.c_float] * 5 + [C.c_void_p, C.c_float,
                                                                                                  C.c_void_p]),
+    "disyolo_adam_fused_workspace": (C.c_size_t, [C.c_int64]),
+    "disyolo_adam_step_fused": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int64, C.c_void_p] + [C.c_float] * 4 +
+                                [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "disyolo_add_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "disyolo_cmdlist_create": (C.c_void_p, []),
     "disyolo_cmdlist_destroy": (None, [C.c_void_p]),
@@ -571,6 +574,17 @@ def lane_sync(src: int, dst: int) -> None:
 def adam_step_dev(w, grad, m, v, n, n_decay, lr, b1, b2, eps, l2, step_counter, grad_scale=1.0) -> None:
     _check(load().disyolo_adam_step_dev(_p(w), _p(grad), _p(m), _p(v), n, n_decay, lr, b1, b2, eps, l2,
                                         _p(step_counter), grad_scale, _stream()), "adam_step_dev")
+
+
+def adam_step_fused(w, grad, m, v, n, n_decay, lr_dev, b1, b2, eps, l2, step_counter, grad_scale, reg_loss_out,
+                    ws: Workspace) -> None:
+    """Adam with lr and t on the device; also writes 0.5*l2*sum(w_decay^2) of the pre-update weights"""
+    _need(lr_dev, torch.float32, "lr_dev")
+    need = load().disyolo_adam_fused_workspace(n)
+    buf = ws.get(need)
+    _check(load().disyolo_adam_step_fused(_p(w), _p(grad), _p(m), _p(v), n, n_decay, _p(lr_dev), b1, b2, eps, l2,
+                                          _p(step_counter), grad_scale, _p(reg_loss_out), _p(buf), buf.numel(),
+                                          _stream()), "adam_step_fused")
 
 
 def add_bf16(src, dst, accumulate: bool) -> None:

@@ -145,11 +145,14 @@ class YOLONet(object):
         self.ws = L.Workspace(self.device)
         self.ws_aux = L.Workspace(self.device)      # scratch of the side lane (weight gradients)
         self.ws_det = L.Workspace(self.device)      # scratch of the detection filter (either lane)
+        self.ws_opt = L.Workspace(self.device)      # partial sums of the optimizer sweep
+        self._reg_fresh = False
         # lock map: stage 1 = conv1-52 locked (shipped source), stage 2 = all trainable
         self.lock = dict(lock) if lock is not None else {i: (stage == 1 and i <= 52) for i in range(1, 83)}
         self.layers = build_topology(self.num_class, self.k)
         self.by_idx = {l.idx: l for l in self.layers}
-        self.learning_rate = cfg.LEARNING_RATE
+        self._lr = float(cfg.LEARNING_RATE)
+        self.lr_dev = None       # device copy read by the optimizer kernel (set in _init_params)
         self.dp = None  # set by enable_data_parallel
         self._prog = None       # recorded command list of one training step
         self._prog_marks = []   # [(command index, layer)] all-reduce trigger points
@@ -185,6 +188,7 @@ class YOLONet(object):
         self.adam_m = torch.zeros(n, dtype=F32, device=dev)
         self.adam_v = torch.zeros(n, dtype=F32, device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)   # Adam's t, device resident
+        self.lr_dev = torch.full((1,), self._lr, dtype=F32, device=dev)
         self.arena_slices: Dict[str, Tuple[int, int]] = {}
         off_d, off_n = 0, n_decay
         self.params: Dict[str, torch.Tensor] = {}
@@ -243,6 +247,20 @@ class YOLONet(object):
 
     def trainable_names(self) -> List[str]:
         return list(self.arena_slices)
+
+    @property
+    def learning_rate(self) -> float:
+        """AdamOptimizer(learning_rate) (train_yolo3_mask.py:38,55).  The optimizer kernel reads it from
+        device memory, so it can be changed between steps of a recorded program -- which the reference's
+        own schedule (train_yolo3_mask.py:130-141) never achieves: its graph captured the initial 1e-4
+        (SURVEY F6)."""
+        return self._lr
+
+    @learning_rate.setter
+    def learning_rate(self, value: float) -> None:
+        self._lr = float(value)
+        if self.lr_dev is not None:
+            self.lr_dev.fill_(self._lr)
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         """Variables under the reference's checkpoint names/shapes (weights, BN gamma/beta/
@@ -483,39 +501,38 @@ class YOLONet(object):
 
     def _forward_layer(self, l, is_training: bool) -> None:
         B = self.B
-        if l is not None:
-            train_bn = is_training and self.training and (not l.lock) and l.kind != "lin"
-            M = B * l.Ho * l.Wo
-            res = self.by_idx[l.shortcut].act if l.shortcut is not None else None
-            if l.idx == 1:
-                if train_bn:
-                    L.conv_first_fwd(self.images, l.w, self._ones32, self._zeros32, l.raw, alpha=1.0)
-                    L.colstats(l.raw, l.stats, M, l.cout)
-                    L.bn_finalize(l.stats, l.stats_rows, l.cout, M, l.gamma, l.beta, l.mm, l.mv, cfg.BN_DECAY,
-                                  cfg.BN_EPSILON, l.scale, l.shift, l.mean, l.rstd)
-                    L.bn_act_fwd(l.raw, l.scale, l.shift, None, l.act, M, l.cout, cfg.ALPHA)
-                else:
-                    if not l.lock and self.training:
-                        L.bn_fold(l.gamma, l.beta, l.mm, l.mv, cfg.BN_EPSILON, l.scale, l.shift)
-                    L.conv_first_fwd(self.images, l.w, l.scale, l.shift, l.act, alpha=cfg.ALPHA)
-                return
-            if l.kind == "lin":
-                L.conv2d_fwd(l.desc)
-            elif train_bn:
-                L.conv2d_fwd(l.desc)                       # raw conv + per-channel partial sums
+        train_bn = is_training and self.training and (not l.lock) and l.kind != "lin"
+        M = B * l.Ho * l.Wo
+        res = self.by_idx[l.shortcut].act if l.shortcut is not None else None
+        if l.idx == 1:
+            if train_bn:
+                L.conv_first_fwd(self.images, l.w, self._ones32, self._zeros32, l.raw, alpha=1.0)
+                L.colstats(l.raw, l.stats, M, l.cout)
                 L.bn_finalize(l.stats, l.stats_rows, l.cout, M, l.gamma, l.beta, l.mm, l.mv, cfg.BN_DECAY,
                               cfg.BN_EPSILON, l.scale, l.shift, l.mean, l.rstd)
-                L.bn_act_fwd(l.raw, l.scale, l.shift, res, l.act, M, l.cout, cfg.ALPHA)
+                L.bn_act_fwd(l.raw, l.scale, l.shift, None, l.act, M, l.cout, cfg.ALPHA)
             else:
-                if self.training and not l.lock:
-                    # a training-mode plan evaluated with is_training=False: moving statistics
+                if not l.lock and self.training:
                     L.bn_fold(l.gamma, l.beta, l.mm, l.mv, cfg.BN_EPSILON, l.scale, l.shift)
-                    d = L.make_conv_desc(self.by_idx[l.src].act, l.wp, l.act, l.k, l.stride,
-                                         x1=self.by_idx[l.src_up].act if l.src_up is not None else None,
-                                         scale=l.scale, shift=l.shift, residual=res, leaky=True, alpha=cfg.ALPHA)
-                    L.conv2d_fwd(d)
-                else:
-                    L.conv2d_fwd(l.desc)
+                L.conv_first_fwd(self.images, l.w, l.scale, l.shift, l.act, alpha=cfg.ALPHA)
+            return
+        if l.kind == "lin":
+            L.conv2d_fwd(l.desc)
+        elif train_bn:
+            L.conv2d_fwd(l.desc)                       # raw conv + per-channel partial sums
+            L.bn_finalize(l.stats, l.stats_rows, l.cout, M, l.gamma, l.beta, l.mm, l.mv, cfg.BN_DECAY,
+                          cfg.BN_EPSILON, l.scale, l.shift, l.mean, l.rstd)
+            L.bn_act_fwd(l.raw, l.scale, l.shift, res, l.act, M, l.cout, cfg.ALPHA)
+        else:
+            if self.training and not l.lock:
+                # a training-mode plan evaluated with is_training=False: moving statistics
+                L.bn_fold(l.gamma, l.beta, l.mm, l.mv, cfg.BN_EPSILON, l.scale, l.shift)
+                d = L.make_conv_desc(self.by_idx[l.src].act, l.wp, l.act, l.k, l.stride,
+                                     x1=self.by_idx[l.src_up].act if l.src_up is not None else None,
+                                     scale=l.scale, shift=l.shift, residual=res, leaky=True, alpha=cfg.ALPHA)
+                L.conv2d_fwd(d)
+            else:
+                L.conv2d_fwd(l.desc)
 
     def _detect(self, det_thresh: float) -> None:
         L.detect(self.by_idx[75].act, self.by_idx[67].act, self.by_idx[59].act, self.B, self.S, self.num_class,
@@ -628,13 +645,15 @@ class YOLONet(object):
     def compute_losses(self, det_thresh: float = cfg.OBJ_THRESHOLD, first_layer: int = 1) -> None:
         """forward (training mode) + detections + both losses and their gradients wrt the
         head logits / score maps (yolo/yolo3_net_pos.py:59-60)."""
+        self._reg_fresh = False
         self._forward_layers(True, first_layer)
         heads = [self.by_idx[75], self.by_idx[67], self.by_idx[59]]
         side = self.use_side_lane
         if side:
-            # detection filter -> RoI selection -> mask loss only feed the mask subnet's backward:
-            # side lane, while the main lane does the YOLO loss and the heads' backward
-            L.lane_sync(0, 1)
+            # detection filter -> RoI selection -> mask loss only feed the mask subnet's backward: side
+            # lane, while the main lane finishes the mask subnet's forward, the YOLO loss and the heads'
+            # backward.  The head logits (59 / 67 / 75) were produced on the side lane itself, so the
+            # filter starts as soon as they exist; only the mask loss waits for the main lane (layer 82)
             L.set_lane(1)
         if self.shuffle_seed is not None:
             L.shuffle_perm(self.perm_det, self.perm_gt, self.B, int(self.shuffle_seed) & 0xffffffff, self.step_dev)
@@ -643,6 +662,8 @@ class YOLONet(object):
         L.mask_rois(self.detections, cfg.MAX_DETECTION, self.true_boxes, cfg.MAX_BOX_PER_IMAGE, self.perm_det,
                     self.perm_gt, self.B, Sm, cfg.MASK_ROI_DET, cfg.MASK_ROI_GT, cfg.MASK_ROI_IOU, self.rois,
                     self.roi_count)
+        if side:
+            L.lane_sync(0, 1)
         m = self.by_idx[82]
         L.psroi_loss(m.act, self.true_masks, cfg.MAX_BOX_PER_IMAGE, self.rois, self.roi_count, self.B, Sm, self.k,
                      self.mask_scale, m.dx, self.mask_loss, self.ws_aux if side else self.ws)
@@ -806,9 +827,11 @@ class YOLONet(object):
         l2 regulariser's gradient (l2*w) is folded in for weights and biases.  The step count
         lives on the device so the whole step can be replayed without host state."""
         if self.n_params:
-            L.adam_step_dev(self.arena, self.grad_arena, self.adam_m, self.adam_v, self.n_params, self.n_decay,
-                            self.learning_rate, cfg.ADAM_BETA1, cfg.ADAM_BETA2, cfg.ADAM_EPSILON, self.l2,
-                            self.step_dev, grad_scale)
+            # one sweep: Adam (+ l2 gradient) and the value of the l2 term for the weights before the update
+            L.adam_step_fused(self.arena, self.grad_arena, self.adam_m, self.adam_v, self.n_params, self.n_decay,
+                              self.lr_dev, cfg.ADAM_BETA1, cfg.ADAM_BETA2, cfg.ADAM_EPSILON, self.l2,
+                              self.step_dev, grad_scale, self.reg_loss if self.n_decay else None, self.ws_opt)
+            self._reg_fresh = True
         if self._pack_table is None:
             jobs = [(l.w, l.wp, l.wdg, l.k, l.cin, l.cout, l.cout_pad) for l in self.layers
                     if not l.lock and l.idx > 1]
@@ -820,7 +843,9 @@ class YOLONet(object):
         """conf + class + coord + mask + l2 term as a device scalar (tf.losses.get_total_loss,
         yolo/yolo3_net_pos.py:61).  Valid after compute_losses(); the l2 term is evaluated on
         the current weights (inside a recorded step: the pre-update weights, like TF)."""
-        if self.n_decay and self._prog is None:
+        if self.n_decay and not self._reg_fresh:
+            # called between compute_losses() and the optimizer: evaluate the l2 term now; after
+            # optimizer_step() / a recorded step reg_loss already holds it (written by the Adam sweep)
             L.l2_loss(self.arena, self.n_decay, self.l2, self.reg_loss, self.ws)
         return self.losses[7] + self.mask_loss[0] + self.reg_loss[0]
 
@@ -855,6 +880,7 @@ class YOLONet(object):
         prog, marks, self._bwd_end = self._record_step(det_thresh, None)
         self.ws.frozen = True
         self.ws_aux.frozen = True
+        self.ws_opt.frozen = True
         self._prog, self._prog_marks = prog, marks
         if graph:
             if self.dp is not None:
@@ -902,8 +928,6 @@ class YOLONet(object):
                     self._forward_layer(l, True)
                 L.set_lane(0)
                 self._use_parity(parity)
-            if self.n_decay:
-                L.l2_loss(self.arena, self.n_decay, self.l2, self.reg_loss, self.ws)
             if self.dp is not None:
                 self.dp.begin_step()
 
@@ -959,7 +983,6 @@ class YOLONet(object):
             self.run_program()
             return self.total_loss() if want_loss else None
         self.compute_losses(det_thresh)
-        loss = self.total_loss() if want_loss else None   # loss of the pre-update weights, like TF
         if self.dp is not None:
             self.dp.begin_step()
             self.backward(self.dp.on_layer_done)
@@ -968,7 +991,9 @@ class YOLONet(object):
         else:
             self.backward()
             self.optimizer_step()
-        return loss
+        # every term is the value for the weights BEFORE the update, like TF's fetch of total_loss
+        # next to the train op (the l2 term comes out of the Adam sweep)
+        return self.total_loss() if want_loss else None
 
     def summaries(self) -> Dict[str, float]:
         """the 7 tf.summary scalars (yolo/yolo3_net_pos.py:62,743-747,860)."""

@@ -248,6 +248,16 @@ int disyolo_adam_step(float* w, const float* grad, float* m, float* v, int64_t n
 int disyolo_adam_step_dev(float* w, const float* grad, float* m, float* v, int64_t n,
                           int64_t n_decay, float lr, float beta1, float beta2, float eps, float l2,
                           int64_t* step_counter, float grad_scale, void* stream);
+/* same, with the learning rate read from device memory too (lr_dev f32[1]: a recorded step follows
+ * the schedule of train_yolo3_mask.py:130-141 by rewriting one float), and -- when reg_loss_out is
+ * not NULL -- the value of the l2 term of total_loss (yolo/yolo3_net_pos.py:38,61),
+ * 0.5*l2*sum(w[0:n_decay]^2) of the weights BEFORE the update, produced by the same sweep
+ * (workspace: disyolo_adam_fused_workspace(n) bytes; deterministic fixed-order partial sums) */
+size_t disyolo_adam_fused_workspace(int64_t n);
+int disyolo_adam_step_fused(float* w, const float* grad, float* m, float* v, int64_t n,
+                            int64_t n_decay, const float* lr_dev, float beta1, float beta2, float eps,
+                            float l2, int64_t* step_counter, float grad_scale, float* reg_loss_out,
+                            void* workspace, size_t workspace_bytes, void* stream);
 /* 0.5*l2*sum(w[0:n]^2) -> out f32[1] (only needed when the loss value is logged) */
 size_t disyolo_l2_workspace(int64_t n);
 int disyolo_l2_loss(const float* w, int64_t n, float l2, float* out, void* workspace,

@@ -473,8 +473,14 @@ def filter_detections(conf_logit, class_logit, pred_norm_coord, batch_window, ob
 # YOLO loss  (yolo/yolo3_net_pos.py:631-747)
 # ---------------------------------------------------------------------------
 def sigmoid_ce(labels: torch.Tensor, logits: torch.Tensor) -> torch.Tensor:
-    """[TF-sem] tf.nn.sigmoid_cross_entropy_with_logits: max(x,0) - x*z + log1p(exp(-|x|))."""
-    return torch.clamp(logits, min=0) - logits * labels + torch.log1p(torch.exp(-torch.abs(logits)))
+    """[TF-sem] tf.nn.sigmoid_cross_entropy_with_logits: max(x,0) - x*z + log1p(exp(-|x|)), written the
+    way TF builds it -- relu = where(x >= 0, x, 0), -|x| = where(x >= 0, -x, x) -- so that autograd at
+    x == 0 exactly gives TF's gradient sigmoid(0) - z = 0.5 - z.  (max/abs would give the subgradient
+    1 - z there: |x|' = 0 in torch.  Found by the GPU known-answer test with logits that are exactly 0.)"""
+    cond = logits >= 0
+    relu = torch.where(cond, logits, torch.zeros_like(logits))
+    neg_abs = torch.where(cond, -logits, logits)
+    return relu - logits * labels + torch.log1p(torch.exp(neg_abs))
 
 
 def loss_yolo(predicts, true_boxes: torch.Tensor, labels_value: Sequence[torch.Tensor]) -> Dict[str, torch.Tensor]:

@@ -54,3 +54,11 @@ for q, rs in byq.items():
     f = [r for r in rs if r["e"] <= tb]
     if w: print("queue %s backward window: busy %.1f of %.1f us (%d kernels)" % (q, busy(w) / 1e3, (ta - tb) / 1e3, len(w)))
     if f: print("queue %s forward+loss window: busy %.1f of %.1f us (%d kernels)" % (q, busy(f) / 1e3, (tb - t0) / 1e3, len(f)))
+# optional: dump the step's kernels in start order (argv[2] = output path)
+if len(sys.argv) > 2:
+    import re
+    with open(sys.argv[2], "w") as f:
+        for r in sorted(step, key=lambda r: r["s"]):
+            n = re.sub(r"\(anonymous namespace\)::|void |HIP_vector_type<[^>]*>|\(.*$", "", r["Kernel_Name"])
+            f.write("%9.1f %7.1f q%s %s grid=%s wg=%s\n" % ((r["s"] - t0) / 1e3, (r["e"] - r["s"]) / 1e3, r["Queue_Id"], n[:70],
+                                                      r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "?"))))
