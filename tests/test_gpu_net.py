@@ -228,6 +228,43 @@ def test_bn_act_bwd_and_small_ops(dev):
     assert rel_err(out, m.float().sum(0)[:24])[0] < 1e-5
 
 
+@pytest.mark.parametrize("rows,Cc", [(2592, 1024), (41472, 128), (10368, 256), (1000, 32), (165888, 32), (777, 200),
+                                     (130, 64), (41472, 64)])
+def test_bn_act_bwd_matches_f64_and_is_deterministic(dev, rows, Cc):
+    """BN backward (yolo/yolo3_net_pos.py:71-107 through TF autodiff) at the network's real shapes (many rows x
+    few channels ... few rows x 1024 channels, a channel count that is no multiple of 64) against an f64
+    reference; repeated launches must agree bit for bit (fixed summation order)."""
+    g = torch.Generator().manual_seed(rows + Cc)
+    x = torch.randn(rows, Cc, generator=g).to(torch.bfloat16)
+    dy = torch.randn(rows, Cc, generator=g).to(torch.bfloat16)
+    gamma = torch.rand(Cc, generator=g) + 0.5
+    beta = torch.randn(Cc, generator=g) * 0.2
+    xd, dyd = x.double(), dy.double()
+    mean = xd.mean(0)
+    var = ((xd - mean) ** 2).mean(0)
+    rstd = 1 / torch.sqrt(var + 1e-5)
+    scale = gamma.double() * rstd
+    shift = beta.double() - mean * scale
+    z = xd * scale.float().double() + shift.float().double()
+    gg = dyd * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, 0.1))
+    xh = (xd - mean.float().double()) * rstd.float().double()
+    want_dbeta, want_dgamma = gg.sum(0), (gg * xh).sum(0)
+    want_dx = scale * (gg - gg.mean(0) - xh * (gg * xh).mean(0))
+    args = [t.float().to(dev) for t in (scale, shift, mean, rstd)]
+    outs = []
+    ws = L.Workspace(dev)
+    for rep in range(6):
+        dx = torch.empty(rows, Cc, dtype=torch.bfloat16, device=dev)
+        dgam, dbet = torch.full((Cc,), float("nan"), device=dev), torch.full((Cc,), float("nan"), device=dev)
+        L.bn_act_bwd(dy.to(dev), x.to(dev), *args, dx, dgam, dbet, rows, Cc, ws)
+        torch.cuda.synchronize()
+        outs.append((dx.clone(), dgam.clone(), dbet.clone()))
+    assert rel_err(outs[0][1], want_dgamma)[0] < 2e-5 and rel_err(outs[0][2], want_dbeta)[0] < 2e-5
+    assert rel_err(outs[0][0], want_dx)[0] < 5e-3
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
+
+
 def test_adam_three_step_trace(dev):
     """TF-form Adam known-answer trace: epsilon outside the bias correction."""
     w = torch.tensor([1.0, -2.0, 0.5, 3.0], device=dev)

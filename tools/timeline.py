@@ -6,7 +6,7 @@ for r in rows:
     r["s"] = int(r["Start_Timestamp"]); r["e"] = int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
 adam = [i for i, r in enumerate(rows) if "adam_dev" in r["Kernel_Name"]]
-i0, i1 = adam[-3], adam[-2]
+i0, i1 = (adam[-3], adam[-2]) if len(adam) >= 3 else (adam[-2], adam[-1])
 # a step = kernels after adam(i0)'s pack kernel .. adam(i1) + pack
 step = rows[i0 + 1:i1 + 2]
 step = [r for r in step if "pack_all" not in r["Kernel_Name"] or r["s"] > rows[i1]["s"]]
