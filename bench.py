@@ -42,6 +42,7 @@ MFMA_PEAK_TFLOPS = 2500.0      # bf16 dense, MI355X_MICROARCH.md "Peak BF16/FP16
 
 
 HBM_PEAK_TBS = 8.0             # spec; ~6.3 TB/s measured copy
+PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"
 
 
 def bound_model(B: int, S: int, stage: int):
@@ -130,20 +131,7 @@ def bench_infer(args, dev, world, rank):
     net.build_infer_program(graph=(args.mode in ("auto", "graph")))
     for _ in range(args.warmup):
         net.infer()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        net.infer()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, regions = repeated(lambda: net.infer(), args.steps, args.repeats, world, dev)
     if rank == 0:
         value = world * B * args.steps / dt
         gf = FWD_GFLOP_PER_IMG_576 * (S / 576.0) ** 2
@@ -161,6 +149,83 @@ def bench_infer(args, dev, world, rank):
             "reference_published": "README.md:23: ~0.1 s/image (10 img/s) on i7-7700 + GTX 1060, incl. host mask crop"}))
     if world > 1:
         dist.destroy_process_group()
+
+
+def timed_region(step, steps: int, world: int, dev) -> float:
+    """EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks (seconds)"""
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def repeated(step, steps: int, repeats: int, world: int, dev):
+    """the timed region repeated; returns (median seconds, all regions)"""
+    ts = [timed_region(step, steps, world, dev) for _ in range(max(1, repeats))]
+    return float(np.median(ts)), ts
+
+
+def secondary_measurements(args, dev):
+    """same process, after the headline (single GPU): the stage-2 train step (all 82 layers trainable) and
+    the B=32 hipGraph-replayed inference of BASELINE.json configs[3]"""
+    out = {}
+    S = args.size
+    try:
+        B = args.batch
+        net = YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=2, seed=0)
+        net.set_batch(synthetic_batch(B, S, seed=4321))
+        net.shuffle_seed = 99
+        if args.autotune == "on":
+            net.autotune()
+        net.build_program()
+        step = lambda: net.train_step(None, want_loss=False)
+        for _ in range(3):
+            step()
+        med, ts = repeated(step, 10, 5, 1, dev)
+        gf = TRAIN_GFLOP_PER_IMG_576[2] * (S / 576.0) ** 2
+        out["train_stage2"] = {"workload": "train_step_B%d_%dx%d_3class_stage2" % (B, S, S), "value": round(B * 10 / med, 2),
+                               "unit": "images/sec", "ms_per_step": round(med / 10 * 1e3, 3), "steps": 10, "repeats": len(ts),
+                               "frac_of_mfma_peak": round(gf * B * 10 / med / 1e3 / MFMA_PEAK_TFLOPS, 4),
+                               "final_total_loss": round(float(net.total_loss().cpu()), 4)}
+        del net
+        torch.cuda.empty_cache()
+    except Exception as e:   # a secondary line must never cost the headline
+        out["train_stage2"] = {"error": repr(e)[:200]}
+    try:
+        B = 32
+        net = YOLONet(training=False, device=dev, image_size=S, batch_size=B, stage=1, seed=0)
+        batch = synthetic_batch(B, S, seed=1234)
+        net._set_inputs(batch["images"], batch["clip_window"])
+        if args.autotune == "on":
+            net.autotune()
+        net.build_infer_program(graph=True)
+        step = lambda: net.infer()
+        for _ in range(3):
+            step()
+        med, ts = repeated(step, 10, 5, 1, dev)
+        gf = FWD_GFLOP_PER_IMG_576 * (S / 576.0) ** 2
+        out["infer_b32_graph"] = {"workload": "infer_B32_%dx%d_3class_hipgraph (network + NMS + PS-RoI mask assembly)" % (S, S),
+                                  "value": round(B * 10 / med, 2), "unit": "images/sec", "ms_per_step": round(med / 10 * 1e3, 3),
+                                  "steps": 10, "repeats": len(ts),
+                                  "frac_of_mfma_peak": round(gf * B * 10 / med / 1e3 / MFMA_PEAK_TFLOPS, 4)}
+        del net
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["infer_b32_graph"] = {"error": repr(e)[:200]}
+    return out
 
 
 def emit(obj) -> None:
@@ -188,6 +253,9 @@ def main():
     ap.add_argument("--task", default="train", choices=("train", "infer"),
                     help="train = the headline metric; infer = BASELINE.json config 4 (forward + detection filter + "
                          "PS-RoI mask assembly, hipGraph replay), reported as a secondary line")
+    ap.add_argument("--repeats", type=int, default=10,
+                    help="the timed region of --steps steps is repeated this often; the reported value is the median")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the stage-2 / B=32 inference lines of 'secondary'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--pipeline", default="auto", choices=("auto", "on", "off"),
@@ -281,22 +349,7 @@ def main():
             net.prime_pipeline()       # backbone of the first batch, outside the timed region
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, regions = repeated(step, args.steps, args.repeats, world, dev)
     loss = float(net.total_loss().cpu())
 
     if rank == 0:
@@ -306,7 +359,9 @@ def main():
         out = {
             "metric": "train images/sec @%dx%d bf16" % (S, S),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "repeats": len(regions),
+            "ms_per_step_min_max": [round(min(regions) / args.steps * 1e3, 3), round(max(regions) / args.steps * 1e3, 3)],
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "train_step_B%d_%dx%d_3class_stage%d" % (B, S, S, args.stage),
                        "images_per_gpu": B, "global_batch": B * world, "image_size": S,
@@ -337,11 +392,12 @@ def main():
             achieved = r["flops_total"] / (r["ms_total"] * 1e-3) / 1e12
             traffic, traffic_src = None, None
             try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc, see the file's "method")
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
                 key = dom.replace(",", ", ")
                 if key in pmc["kernels"]:
                     traffic = pmc["kernels"][key]["hbm_mb_per_launch_corrected"] * 1e6
-                    traffic_src = "profiles/r01h_pmc_traffic.json"
+                    traffic_src = "profiles/%s (separate rocprofv3 --pmc passes of this command at %s)" % (
+                        PMC_TRAFFIC_FILE, pmc.get("measured_at", "?"))
             except Exception:
                 pass
             out["roofline"] = {"bound": "mfma", "kernel": dom, "timed_with": "HIP events, %d eager steps of the same workload" % args.steps, "achieved": round(achieved, 1),
@@ -353,6 +409,9 @@ def main():
                                "avg_launch_us": round(r["ms_total"] / r["launches"] * 1e3, 2),
                                "launches_per_step": r["launches"] / args.steps}
             out["kernels"] = kernels
+        if world == 1 and not args.no_secondary and args.stage == 1 and B == 8:
+            del timer
+            out["secondary"] = secondary_measurements(args, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.stage, S)
         emit(out)

@@ -679,6 +679,19 @@ extern "C" size_t disyolo_conv2d_wgrad_workspace(const disyolo_conv_desc* d) {
   return (size_t)splits * K * d->Cout * sizeof(float);
 }
 
+extern "C" int disyolo_conv2d_wgrad_plan(const disyolo_conv_desc* d, int* kind, int* tile_n, int* ring, int* splits) {
+  if (!d || !kind || !tile_n || !ring || !splits) return DISYOLO_E_ARG;
+  Plan3 q;
+  if (plan3(d, &q)) {
+    *kind = 1; *tile_n = q.co_t; *ring = q.R; *splits = q.splits;
+    return DISYOLO_OK;
+  }
+  int bn, sp, sps, steps;
+  plan(d, &bn, &sp, &sps, &steps);
+  *kind = 0; *tile_n = bn; *ring = 0; *splits = sp;
+  return DISYOLO_OK;
+}
+
 extern "C" int disyolo_conv2d_wgrad(const disyolo_conv_desc* d, const void* dy, int dy_ld, float* dw, void* workspace,
                                     size_t workspace_bytes, void* stream) {
   DY_REQUIRE(d && dy && dw, "wgrad: null pointer");
@@ -715,6 +728,7 @@ extern "C" int disyolo_conv2d_wgrad(const disyolo_conv_desc* d, const void* dy, 
     static const int dbg = env_int("DISYOLO_WG3_DEBUG", 0);
     p.debug = dbg;
     hipStream_t s = (hipStream_t)stream;
+    if (d->tile & 0x400) goto reduce3;
     if (q3.co_t == 128) {
       if (q3.R == 8) launch3<128, 8>(p, q3, s);
       else if (q3.R == 16) launch3<128, 16>(p, q3, s);
@@ -725,7 +739,8 @@ extern "C" int disyolo_conv2d_wgrad(const disyolo_conv_desc* d, const void* dy, 
       else launch3<64, 32>(p, q3, s);
     }
     DY_CHECK_LAUNCH();
-    if (q3.splits > 1) {
+  reduce3:
+    if (q3.splits > 1 && !(d->tile & 0x200)) {
       const int64_t n = (int64_t)9 * p.Cin * p.Cout;
       hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(n, 64)), dim3(256), 0, s, (const float*)workspace, dw, n,
                          q3.splits);
@@ -753,7 +768,8 @@ extern "C" int disyolo_conv2d_wgrad(const disyolo_conv_desc* d, const void* dy, 
   p.tilesN = ceil_div(p.Cout, bn);
   dim3 grid(p.tilesK * p.tilesN * splits);
   // pipeline depth: d->tile (1..3 -> 2..4 stages) overrides the default (tuning)
-  const int st = (d->tile >= 1 && d->tile <= 3) ? d->tile + 1 : 3;
+  const int st = ((d->tile & 0xff) >= 1 && (d->tile & 0xff) <= 3) ? (d->tile & 0xff) + 1 : 3;
+  if (d->tile & 0x400) goto reduce1;
 #define DY_WG(BNV, YB)                                                                                   \
   if (st == 2) hipLaunchKernelGGL((conv_wgrad_kernel<BNV, 2>), grid, dim3(256), 2 * (8192 + YB), s, p);      \
   else if (st == 3) hipLaunchKernelGGL((conv_wgrad_kernel<BNV, 3>), grid, dim3(256), 3 * (8192 + YB), s, p); \
@@ -763,7 +779,8 @@ extern "C" int disyolo_conv2d_wgrad(const disyolo_conv_desc* d, const void* dy, 
   else { DY_WG(32, 4096) }
 #undef DY_WG
   DY_CHECK_LAUNCH();
-  if (splits > 1) {
+reduce1:
+  if (splits > 1 && !(d->tile & 0x200)) {
     const int64_t n = (int64_t)p.K * p.Cout;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(n, 64)), dim3(256), 0, s, (const float*)workspace, dw, n,
                        splits);

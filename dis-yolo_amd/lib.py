@@ -51,6 +51,7 @@ _SIGS = {
     "disyolo_conv2d_wgrad_workspace": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "disyolo_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_size_t, C.c_void_p]),
+    "disyolo_conv2d_wgrad_plan": (C.c_int, [C.POINTER(ConvDesc)] + [C.POINTER(C.c_int)] * 4),
     "disyolo_conv_first_wgrad_workspace": (C.c_size_t, [C.c_int] * 4),
     "disyolo_conv_first_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "disyolo_image_pad8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -389,13 +390,31 @@ def conv2d_wgrad(d: ConvDesc, dy, dy_ld: int, dw, ws: Workspace) -> None:
     need = load().disyolo_conv2d_wgrad_workspace(C.byref(d))
     buf = ws.get(need)
     if TIMER is not None:
-        name = "conv_wgrad_kernel<%d,3>" % (128 if d.Cout > 64 else (64 if d.Cout > 32 else 32))
-        TIMER.run(name, conv_flops(d), lambda: _check(
-            load().disyolo_conv2d_wgrad(C.byref(d), _p(dy), dy_ld, _p(dw), _p(buf), buf.numel(), _stream()),
-            "conv2d_wgrad"))
+        # the partial-sum kernel and the slab reduction as two timed launches (same work, same order)
+        kind, tn, ring, splits = conv2d_wgrad_plan(d)
+        name = ("conv_wgrad3x3_kernel<%d,%d,3>" % (tn, ring)) if kind == 1 else ("conv_wgrad_kernel<%d,3>" % tn)
+        keep = d.tile
+
+        def phase(bits):
+            d.tile = keep | bits
+            try:
+                _check(load().disyolo_conv2d_wgrad(C.byref(d), _p(dy), dy_ld, _p(dw), _p(buf), buf.numel(), _stream()),
+                       "conv2d_wgrad")
+            finally:
+                d.tile = keep
+        TIMER.run(name, conv_flops(d), lambda: phase(0x200))
+        if splits > 1:
+            TIMER.run("slab_reduce_kernel", 0.0, lambda: phase(0x400))
         return
     _check(load().disyolo_conv2d_wgrad(C.byref(d), _p(dy), dy_ld, _p(dw), _p(buf), buf.numel(), _stream()),
            "conv2d_wgrad")
+
+
+def conv2d_wgrad_plan(d: ConvDesc):
+    """(kind, channel tile, ring slots, pixel splits) of the weight-gradient launch for this descriptor"""
+    v = [C.c_int(0) for _ in range(4)]
+    _check(load().disyolo_conv2d_wgrad_plan(C.byref(d), *[C.byref(x) for x in v]), "conv2d_wgrad_plan")
+    return tuple(x.value for x in v)
 
 
 def conv_first_wgrad(images, dy, dw, ws: Workspace) -> None:

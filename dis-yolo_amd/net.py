@@ -116,7 +116,7 @@ def var_name(i: int, leaf: str) -> str:
 class YOLONet(object):
     def __init__(self, training: bool = False, device=None, image_size: Optional[int] = None,
                  batch_size: Optional[int] = None, stage: int = 1, lock: Optional[Dict[int, bool]] = None,
-                 seed: int = 0, xavier_locked: bool = True):
+                 seed: int = 0, xavier_locked: bool = True, plan_only: bool = False):
         # 1. parameters (yolo/yolo3_net_pos.py:15-38)
         self.batchsize = int(batch_size if batch_size is not None else cfg.BATCH_SIZE)
         self.classes = cfg.CLASSES
@@ -136,16 +136,23 @@ class YOLONet(object):
         self.image_size = int(image_size if image_size is not None else cfg.IMAGE_SIZE)
         if self.image_size % 32:
             raise ValueError("image size must be a multiple of 32")
+        # plan_only: variables, parameter arena and layer table only (any device, no kernel library) --
+        # what checkpoint tools and the CPU tests of the data-parallel protocol need; it cannot compute
+        self.plan_only = bool(plan_only)
         if device is None:
-            if not torch.cuda.is_available():
+            if self.plan_only:
+                device = torch.device("cpu")
+            elif not torch.cuda.is_available():
                 raise L.DisyoloError("YOLONet needs a GPU: the HIP kernels have no CPU fallback")
-            device = torch.device("cuda", torch.cuda.current_device())
+            else:
+                device = torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
-        L.load()
-        self.ws = L.Workspace(self.device)
-        self.ws_aux = L.Workspace(self.device)      # scratch of the side lane (weight gradients)
-        self.ws_det = L.Workspace(self.device)      # scratch of the detection filter (either lane)
-        self.ws_opt = L.Workspace(self.device)      # partial sums of the optimizer sweep
+        if not self.plan_only:
+            L.load()
+            self.ws = L.Workspace(self.device)
+            self.ws_aux = L.Workspace(self.device)      # scratch of the side lane (weight gradients)
+            self.ws_det = L.Workspace(self.device)      # scratch of the detection filter (either lane)
+            self.ws_opt = L.Workspace(self.device)      # partial sums of the optimizer sweep
         self._reg_fresh = False
         # lock map: stage 1 = conv1-52 locked (shipped source), stage 2 = all trainable
         self.lock = dict(lock) if lock is not None else {i: (stage == 1 and i <= 52) for i in range(1, 83)}
@@ -164,7 +171,8 @@ class YOLONet(object):
         # weight gradients of the last layers of the backward pass stay on the main lane (tuned below)
         self.tail_on_main = int(os.environ.get("DISYOLO_TAIL_MAIN", "0"))
         self._init_params(seed, xavier_locked)
-        self._plan(self.batchsize, self.image_size)
+        if not self.plan_only:
+            self._plan(self.batchsize, self.image_size)
 
     # ------------------------------------------------------------------ parameters
     def _init_params(self, seed: int, xavier_locked: bool) -> None:
@@ -278,7 +286,8 @@ class YOLONet(object):
             missing = set(self.params) - set(sd)
             if missing:
                 raise KeyError("missing variables: %s" % sorted(missing)[:4])
-        self.refresh_weights()
+        if not self.plan_only:
+            self.refresh_weights()
 
     # ------------------------------------------------------------------ static plan
     def _plan(self, B: int, S: int) -> None:
@@ -683,6 +692,12 @@ class YOLONet(object):
                              residual=None if (first or "tmp" in desc_kw) else tgt.grad)
         L.conv2d_fwd(d)
 
+    def backward_order(self) -> List[Layer]:
+        """the order backward() visits the layers in: the three detection heads (75,74 / 67,66 / 59,58)
+        first, then the rest in descending order (any topological order of the reversed graph is valid)"""
+        heads = [self.by_idx[i] for i in (75, 74, 67, 66, 59, 58)]
+        return heads + [l for l in reversed(self.layers) if l.idx not in self.HEAD_LAYERS]
+
     def backward(self, on_layer_done=None) -> None:
         """TF autodiff of total_loss restated layer by layer in reverse order.  Gradients of
         the trainable variables land in ``grad_arena``.  ``on_layer_done(layer)`` is called
@@ -694,10 +709,9 @@ class YOLONet(object):
         # any topological order of the reversed graph is valid.  The three detection heads
         # (75,74 / 67,66 / 59,58) depend on the YOLO loss only, so they go first while the side
         # lane still runs the detection filter and the mask loss; the mask subnet follows.
-        heads = [self.by_idx[i] for i in (75, 74, 67, 66, 59, 58)]
-        rest = [l for l in reversed(self.layers) if l.idx not in self.HEAD_LAYERS]
-        order = [l for l in heads + rest if not l.lock]
-        for l in heads + rest:
+        visit = self.backward_order()
+        order = [l for l in visit if not l.lock]
+        for l in visit:
             pos = order.index(l) if not l.lock else -1
             if l.idx == 82 and getattr(self, "_mask_loss_pending", False):
                 L.lane_sync(1, 0)          # dscore comes from the side lane

@@ -103,6 +103,11 @@ size_t disyolo_conv2d_wgrad_workspace(const disyolo_conv_desc* d);
 int disyolo_conv2d_wgrad(const disyolo_conv_desc* d, const void* dy, int dy_ld, float* dw,
                          void* workspace, size_t workspace_bytes, void* stream);
 /* same for the first layer (f32 image input, Cin = 3): dw f32 [3,3,3,Cout] */
+/* which kernel the launcher picks for this descriptor: kind 0 = im2col kernel (tile_n = channel tile),
+ * 1 = tap-fused 3x3 kernel (tile_n = channel tile, ring = input ring slots); splits = pixel splits
+ * (f32 slabs summed by slab_reduce when > 1).  desc.tile bit 0x100 forces the im2col kernel; bits
+ * 0x200 / 0x400 launch only the partial-sum kernel / only the slab reduction (per-kernel timing). */
+int disyolo_conv2d_wgrad_plan(const disyolo_conv_desc* d, int* kind, int* tile_n, int* ring, int* splits);
 size_t disyolo_conv_first_wgrad_workspace(int B, int H, int W, int Cout);
 int disyolo_conv_first_wgrad(const float* images, const void* dy, float* dw, int B, int H, int W,
                              int Cout, void* workspace, size_t workspace_bytes, void* stream);

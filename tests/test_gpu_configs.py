@@ -221,6 +221,35 @@ def test_config2_one_rank_rccl_step_equals_plain_step(dev, one_rank_rccl, pipeli
             assert torch.equal(n.params[name], plain.params[name]), name
 
 
+@pytest.mark.parametrize("wire,algo", [("f32", "rs_ag"), ("bf16", "allreduce"), ("bf16", "rs_ag")])
+def test_config2_wire_formats_and_reduce_scatter_variant(dev, one_rank_rccl, wire, algo):
+    """the exchange options of dp.py on one RCCL rank: reduce-scatter + all-gather of an f32 bucket is the
+    identity (bit-identical step); the bf16 wire rounds the gradient to 8 significant bits once, so after
+    one Adam step (|dw| <= lr) the weights agree to a fraction of lr"""
+    from disyolo_amd.dp import enable_data_parallel
+    B, S = 2, 64
+    batch = O.synthetic_batch(B, S, seed=71)
+    nets = [YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=1, seed=3) for _ in range(2)]
+    for n in nets:
+        seeded_heads(n, 31, gain=6.0, bias_std=0.5)
+        n.shuffle_seed = 5
+        n.set_batch(batch)
+    plain, dpn = nets
+    enable_data_parallel(dpn, bucket_mb=4.0, wire=wire, algo=algo)
+    plain.build_program(det_thresh=0.1)
+    dpn.build_program(det_thresh=0.1)
+    for _ in range(2):
+        l0 = float(plain.train_step(None).cpu())
+        l1 = float(dpn.train_step(None).cpu())
+        assert l0 == l1 or wire == "bf16"
+    torch.cuda.synchronize()
+    if wire == "f32":
+        assert torch.equal(plain.arena, dpn.arena) and torch.equal(plain.adam_v, dpn.adam_v)
+    else:
+        assert float((plain.arena - dpn.arena).abs().max()) < 0.5 * cfg.LEARNING_RATE
+        assert rel_l2(dpn.grad_arena, plain.grad_arena) < 2 ** -8
+
+
 def test_bf16_gradient_storage_along_the_residual_trunk(dev):
     """Stage 2, 192x192, B=2: weight gradients of conv1-10 (the far end of 23 residual blocks whose
     trunk gradient is rounded to bf16 once per block) and of conv43-52 (the near end) against the oracle
