@@ -1,4 +1,5 @@
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 #include "common.h"
 #include "runtime.h"
@@ -37,6 +38,40 @@ __global__ __launch_bounds__(256) void add_bf16_kernel(const uint4* src, uint4* 
   }
 }
 }  // namespace
+
+// CRC-32C (Castagnoli), slicing-by-8: host helper of the checkpoint writer / reader (TensorFlow tensor
+// bundles carry a masked crc32c per tensor and per index block; a 247 MB stage-2 checkpoint takes ~0.2 s)
+namespace {
+struct Crc32cTables {
+  uint32_t t[8][256];
+  Crc32cTables() {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1) ? 0x82F63B78u : 0u);
+      t[0][i] = c;
+    }
+    for (int k = 1; k < 8; ++k)
+      for (uint32_t i = 0; i < 256; ++i) t[k][i] = (t[k - 1][i] >> 8) ^ t[0][t[k - 1][i] & 0xff];
+  }
+};
+}  // namespace
+extern "C" uint32_t disyolo_crc32c(const void* data, size_t n, uint32_t crc) {
+  static const Crc32cTables T;
+  const unsigned char* p = (const unsigned char*)data;
+  uint32_t c = crc ^ 0xffffffffu;
+  while (n >= 8) {
+    uint32_t a, b;
+    memcpy(&a, p, 4);
+    memcpy(&b, p + 4, 4);
+    a ^= c;
+    c = T.t[7][a & 0xff] ^ T.t[6][(a >> 8) & 0xff] ^ T.t[5][(a >> 16) & 0xff] ^ T.t[4][a >> 24] ^ T.t[3][b & 0xff] ^
+        T.t[2][(b >> 8) & 0xff] ^ T.t[1][(b >> 16) & 0xff] ^ T.t[0][b >> 24];
+    p += 8;
+    n -= 8;
+  }
+  while (n--) c = T.t[0][(c ^ *p++) & 0xff] ^ (c >> 8);
+  return c ^ 0xffffffffu;
+}
 
 bool dy_recording() { return g_rec != nullptr; }
 int dy_record(std::function<int(void*)> fn) {

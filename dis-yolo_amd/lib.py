@@ -107,6 +107,7 @@ _SIGS = {
     "disyolo_cmdlist_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "disyolo_cmdlist_run_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "disyolo_cmdlist_side_stream": (C.c_void_p, [C.c_void_p]),
+    "disyolo_crc32c": (C.c_uint32, [C.c_void_p, C.c_size_t, C.c_uint32]),
     "disyolo_l2_workspace": (C.c_size_t, [C.c_int64]),
     "disyolo_l2_loss": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }

@@ -272,6 +272,12 @@ int disyolo_l2_loss(const float* w, int64_t n, float l2, float* out, void* works
  * shortcuts (yolo/yolo3_net_pos.py:150) */
 int disyolo_add_bf16(const void* src, void* dst, int64_t n, int accumulate, void* stream);
 
+/* ---- host helper of the checkpoint reader / writer (dis-yolo_amd/checkpoint.py; train_yolo3_mask.py:58,
+ * 221-226 Saver.save / calculate_test_map.py:184-185 Saver.restore): CRC-32C (Castagnoli) of n bytes,
+ * continuing from `crc` (0 to start) -- TensorFlow tensor bundles store it masked per tensor and per
+ * index block.  Runs on the host; no device work. */
+uint32_t disyolo_crc32c(const void* data, size_t n, uint32_t crc);
+
 /* ---- command lists: the native step executor ----
  * Between cmdlist_begin and cmdlist_end every launch entry point above, called from the
  * recording thread, appends itself to the list (arguments captured by value; device buffers
