@@ -344,6 +344,42 @@ __global__ __launch_bounds__(256) void mask_paste_kernel(const float* masks, int
 }
 
 
+// image_read (calculate_test_map.py:149-176, utils/val_data.py:36-63): aspect-preserving bilinear
+// resize of an RGB uint8 image (as float32, like cv2.resize(image.astype(float32), INTER_LINEAR))
+// centred in a size x size letter box padded with 127, then / 255.  Same tap arithmetic as the mask
+// paste above (aligned pixel centres, clamped border taps with weight 0, horizontal then vertical
+// pass, float32 without FMA).  One thread per output pixel; the three channels together.
+__global__ __launch_bounds__(256) void letterbox_kernel(const unsigned char* rgb, int H, int W, float* out, int size,
+                                                        int new_h, int new_w, int top, int left) {
+  const int64_t total = (int64_t)size * size;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int y = (int)(i / size), x = (int)(i - (int64_t)y * size);
+    float v[3] = {127.f, 127.f, 127.f};
+    if (y >= top && y < top + new_h && x >= left && x < left + new_w) {
+      float fx = (float)(((double)(x - left) + 0.5) * ((double)W / (double)new_w) - 0.5);
+      float fy = (float)(((double)(y - top) + 0.5) * ((double)H / (double)new_h) - 0.5);
+      int sx = (int)floorf(fx), sy = (int)floorf(fy);
+      float ax = __fsub_rn(fx, (float)sx), ay = __fsub_rn(fy, (float)sy);
+      if (sx < 0) { ax = 0.f; sx = 0; }
+      if (sx >= W - 1) { ax = 0.f; sx = W - 1; }
+      if (sy < 0) { ay = 0.f; sy = 0; }
+      if (sy >= H - 1) { ay = 0.f; sy = H - 1; }
+      const int sx1 = min(sx + 1, W - 1), sy1 = min(sy + 1, H - 1);
+      const unsigned char* r0 = rgb + ((size_t)sy * W) * 3;
+      const unsigned char* r1 = rgb + ((size_t)sy1 * W) * 3;
+      const float bx = __fsub_rn(1.f, ax), by = __fsub_rn(1.f, ay);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float h0 = __fadd_rn(__fmul_rn((float)r0[sx * 3 + c], bx), __fmul_rn((float)r0[sx1 * 3 + c], ax));
+        const float h1 = __fadd_rn(__fmul_rn((float)r1[sx * 3 + c], bx), __fmul_rn((float)r1[sx1 * 3 + c], ax));
+        v[c] = __fadd_rn(__fmul_rn(h0, by), __fmul_rn(h1, ay));
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[i * 3 + c] = (float)__ddiv_rn((double)v[c], 255.0);   // new_image / 255.0 in float64 (a plain "/" is narrowed to an approximate f32 division)
+  }
+}
+
 // 4x4 pixel confusion counts of two uint8 class maps (calculate_test_map.py:303-331): per-block LDS
 // histogram, integer atomics into the caller's int64[16] accumulator (exact, order-independent)
 __global__ __launch_bounds__(256) void confusion16_kernel(const unsigned char* t, const unsigned char* p, int64_t n,
@@ -452,6 +488,35 @@ extern "C" int disyolo_mask_paste(const float* masks, int n, int size, const int
   if (grid > 256 * 16) grid = 256 * 16;
   hipLaunchKernelGGL(mask_paste_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, masks, n, size, (const int*)rects,
                      (const int*)classids, image_h, image_w, (unsigned char*)full_masks, (unsigned char*)merged);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+extern "C" int disyolo_letterbox(const uint8_t* rgb, int image_h, int image_w, float* out, int size, float* window_host,
+                                 void* stream) {
+  DY_REQUIRE(rgb && out && image_h > 0 && image_w > 0 && size > 0, "letterbox: bad args");
+  int new_h, new_w;
+  if (((double)size / image_w) < ((double)size / image_h)) {   // Python float division
+    new_h = (int)(((int64_t)image_h * size) / image_w);
+    new_w = size;
+  } else {
+    new_w = (int)(((int64_t)image_w * size) / image_h);
+    new_h = size;
+  }
+  DY_REQUIRE(new_h > 0 && new_w > 0, "letterbox: degenerate image");
+  const int top = (size - new_h) / 2, left = (size - new_w) / 2;
+  if (window_host) {   // [top, left, bottom, right] normalised, float32 of the float64 quotient like numpy
+    window_host[0] = (float)((double)top / size);
+    window_host[1] = (float)((double)left / size);
+    window_host[2] = (float)((double)(new_h + top) / size);
+    window_host[3] = (float)((double)(new_w + left) / size);
+  }
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_letterbox(rgb, image_h, image_w, out, size, nullptr, s); });
+  const int64_t total = (int64_t)size * size;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(letterbox_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, rgb, image_h, image_w, out, size,
+                     new_h, new_w, top, left);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }

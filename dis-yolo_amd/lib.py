@@ -88,6 +88,7 @@ _SIGS = {
     "disyolo_psroi_assemble": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 3),
     "disyolo_mask_paste": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
+    "disyolo_letterbox": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "disyolo_confusion16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "disyolo_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int64] + [C.c_float] * 5 + [C.c_int64, C.c_float,
                                                                                              C.c_void_p]),
@@ -509,6 +510,19 @@ def mask_paste(masks, rects, classids, image_h: int, image_w: int, full_masks, m
     _check(load().disyolo_mask_paste(_p(masks) if n else None, n, int(masks.shape[-1]) if n else 1, _p(rects) if n else None,
                                      _p(classids) if n else None, image_h, image_w, _p(full_masks), _p(merged), _stream()),
            "mask_paste")
+
+
+def letterbox(rgb_u8, out, size: int):
+    """rgb_u8 uint8 CUDA [H,W,3] -> out f32 CUDA [size,size,3]; returns the clip window (numpy f32 [4])"""
+    import numpy as np
+    _need(rgb_u8, torch.uint8, "rgb")
+    _need(out, torch.float32, "out")
+    if rgb_u8.dim() != 3 or rgb_u8.shape[2] != 3 or tuple(out.shape) != (size, size, 3):
+        raise DisyoloError("letterbox: rgb must be [H,W,3] uint8 and out [size,size,3] f32")
+    win = (C.c_float * 4)()
+    _check(load().disyolo_letterbox(_p(rgb_u8), int(rgb_u8.shape[0]), int(rgb_u8.shape[1]), _p(out), size, win, _stream()),
+           "letterbox")
+    return np.array(list(win), np.float32)
 
 
 def confusion16(true_map, pred_map, conf) -> None:

@@ -1,0 +1,198 @@
+"""Training driver: the counterpart of ``train_yolo3_mask.py`` (class ``Solver`` :20-235, ``main`` :237-248).
+
+Same loop as the reference: every step ``data.get()`` -> ``sess.run([total_loss, optimizer])``; every
+SUMMARY_ITER steps the seven summary scalars; every 10 * SUMMARY_ITER steps a full validation sweep
+(``net.evaluation`` per batch -> ``MAP.do_python_eval``) and a log line; every SAVE_ITER steps a TF-format
+checkpoint ``model.ckpt-<step>`` of the ``yolo/convolutional{1..82}`` variables plus ``<step>map.npy``.
+
+Differences, all deliberate and switchable:
+  * the step is the recorded HIP program of ``YOLONet`` (one C call per step) instead of a TF session;
+  * the learning rate.  In the reference the schedule of :130-141 is dead code: the optimizer captured
+    1e-4 when the graph was built (:38,55) and the later assignments only change what is printed
+    (SURVEY F6).  ``lr_schedule="faithful"`` (default) therefore trains at 1e-4 and prints the
+    schedule's value like the reference; ``"intended"`` applies it (the optimizer kernel reads the rate
+    from device memory, so the recorded step follows it);
+  * summaries go to ``events.jsonl`` in the checkpoint directory (no TensorBoard writer here).
+"""
+from __future__ import annotations
+
+import datetime
+import json
+import os
+import time
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import config as cfg
+from .checkpoint import restore_net, save_net
+
+
+class Timer(object):
+    """utils/timer.py:3-37"""
+
+    def __init__(self):
+        self.init_time = time.time()
+        self.total_time = 0.0
+        self.calls = 0
+        self.start_time = 0.0
+        self.diff = 0.0
+        self.average_time = 0.0
+        self.remain_time = 0.0
+
+    def tic(self):
+        self.start_time = time.time()
+
+    def toc(self, average=True):
+        self.diff = time.time() - self.start_time
+        self.total_time += self.diff
+        self.calls += 1
+        self.average_time = self.total_time / self.calls
+        return self.average_time if average else self.diff
+
+    def remain(self, iters, max_iters):
+        if iters == 0:
+            self.remain_time = 0
+        else:
+            self.remain_time = (time.time() - self.init_time) * (max_iters - iters) / iters
+        return str(datetime.timedelta(seconds=int(self.remain_time)))
+
+
+def scheduled_learning_rate(step: int) -> float:
+    """the values train_yolo3_mask.py:130-141 assigns (and, in the reference, only prints)"""
+    if step <= 10000:
+        return 1e-3
+    if step <= 20000:
+        return 1e-4
+    if step <= 25000:
+        return 1e-5
+    return 1e-6
+
+
+class Solver(object):
+    def __init__(self, net, data, evalu=None, val_data=None, output_dir: Optional[str] = None,
+                 lr_schedule: str = "faithful", restore_weight: Optional[str] = None, stage: int = 1,
+                 max_iter: Optional[int] = None, summary_iter: Optional[int] = None, save_iter: Optional[int] = None,
+                 log: Callable[[str], None] = print, use_program: bool = True):
+        """net: YOLONet(training=True); data: object with ``get()`` -> (images, true_masks, true_boxes, yolo_3,
+        yolo_2, yolo_1, window) and attributes epoch / image_size / batch_size (utils/train_data.py:44-276);
+        evalu: ``MAP``; val_data: object with ``get()`` -> (images [N,S,S,3], image ids, windows [N,4])
+        (utils/val_data.py:23-34); restore_weight: checkpoint prefix (cfg.WEIGHTS_FILE in the reference)."""
+        if lr_schedule not in ("faithful", "intended"):
+            raise ValueError("lr_schedule must be 'faithful' or 'intended'")
+        self.net, self.data, self.eval, self.val_data = net, data, evalu, val_data
+        self.start_iter = 1
+        self.max_iter = cfg.MAX_ITER if max_iter is None else max_iter
+        self.summary_iter = cfg.SUMMARY_ITER if summary_iter is None else summary_iter
+        self.save_iter = cfg.SAVE_ITER if save_iter is None else save_iter
+        out = cfg.OUTPUT_DIR if output_dir is None else output_dir
+        self.ckpt_dir = os.path.join(out, "checkpoint")
+        self.loss_dir = os.path.join(out, "lossnp")
+        self.ckpt_file = os.path.join(self.ckpt_dir, "model.ckpt")
+        os.makedirs(self.ckpt_dir, exist_ok=True)
+        os.makedirs(self.loss_dir, exist_ok=True)
+        self.save_cfg()
+        self.lr_schedule = lr_schedule
+        self.learning_rate = 1e-4                 # :38 -- what the optimizer uses in "faithful" mode
+        self.log = log
+        self.use_program = use_program
+        self.global_step = 0
+        self.events = open(os.path.join(self.ckpt_dir, "events.jsonl"), "a")
+        self.log("*** Train variables ***")
+        for i, name in enumerate(net.trainable_names()):
+            self.log("  param {:3}: {:15}   {}".format(i, str(tuple(net.params[name].shape)), name))
+        if restore_weight:
+            self.log("Restoring weights from: " + restore_weight)
+            # stage 1: the include list of :75-107 (ignore_missing_vars); stage 2: everything (:111)
+            restore_net(net, restore_weight, stage1_include=(stage == 1))
+        net.learning_rate = self.learning_rate
+
+    def save_cfg(self):
+        """train_yolo3_mask.py:229-235"""
+        with open(os.path.join(self.ckpt_dir, "config.txt"), "w") as f:
+            for key in sorted(cfg.__dict__.keys()):
+                if key[0].isupper():
+                    f.write("{}: {}\n".format(key, cfg.__dict__[key]))
+
+    def _feed(self):
+        images, true_masks, true_boxes, yolo_3, yolo_2, yolo_1, window = self.data.get()
+        return {"images": images, "true_masks": true_masks, "true_boxes": true_boxes, "yolo3": yolo_3, "yolo2": yolo_2,
+                "yolo1": yolo_1, "clip_window": window}
+
+    def validate(self):
+        """the sweep of :164-178; returns thresh_out[0]"""
+        imagesval, imageidsval, window_vals = self.val_data.get()
+        num_val, B = len(imageidsval), self.net.B
+        if num_val % B:
+            self.log("Please manually change the number of validation data.")      # :123-124
+        detect = []
+        for v in range(num_val // B):
+            a, b = B * v, B * v + B
+            det_boxes, det_masks = self.net.evaluation(imagesval[a:b], window_vals[a:b], [np.float32(cfg.OBJ_THRESHOLD)],
+                                                       masks_on_device=True)
+            detect.extend({"boxes": det_boxes[i], "masks": det_masks[i], "imname": imageidsval[a + i]} for i in range(B))
+        return self.eval.do_python_eval(detect)[0]
+
+    def train(self):
+        load_timer, train_timer = Timer(), Timer()
+        val_map = np.zeros((800, 9))
+        epoch_loss = 0.0
+        net = self.net
+        if self.use_program and net._prog is None:
+            net.set_batch(self._feed_peek())
+            net.build_program(det_thresh=cfg.OBJ_THRESHOLD)
+        history = []
+        for step in range(self.start_iter, self.max_iter + 1):
+            shown_lr = scheduled_learning_rate(step)
+            if self.lr_schedule == "intended":
+                self.learning_rate = shown_lr
+                net.learning_rate = shown_lr
+            load_timer.tic()
+            feed = self._next_feed()
+            load_timer.toc()
+            train_timer.tic()
+            loss = float(net.train_step(feed, det_thresh=cfg.OBJ_THRESHOLD).cpu())
+            train_timer.toc()
+            self.global_step += 1
+            epoch_loss += loss
+            history.append(loss)
+            if step % self.summary_iter == 0:
+                summ = net.summaries()
+                summ["step"] = step
+                self.events.write(json.dumps(summ) + "\n")
+                self.events.flush()
+                if step % (self.summary_iter * 10) == 0 and self.eval is not None and self.val_data is not None:
+                    thresh_out = self.validate()
+                    record_loss = epoch_loss / self.save_iter
+                    row = int(step / (self.summary_iter * 10)) - 1
+                    if row < val_map.shape[0]:
+                        val_map[row, :] = [step, getattr(self.data, "epoch", 0), record_loss] + list(thresh_out["AP"][:3]) + \
+                            list(thresh_out["mAP"][:3])
+                    self.log(("{} Epoch: {}, Step: {}, Image: {}, Batch: {}, Learning rate: {},"
+                              " Loss: {:5.3f}, crack: {:5.3f}, spall: {:5.3f}, rebar: {:5.3f}, mAP50: {:5.3f},"
+                              "\nSpeed: {:.3f}s/iter, Load: {:.3f}s/iter, Remain: {}").format(
+                        datetime.datetime.now().strftime("%m/%d %H:%M:%S"), getattr(self.data, "epoch", 0), int(step),
+                        getattr(self.data, "image_size", net.S), getattr(self.data, "batch_size", net.B),
+                        round(shown_lr, 6), record_loss, thresh_out["AP"][0], thresh_out["AP"][1], thresh_out["AP"][2],
+                        thresh_out["mAP"][2], train_timer.average_time, load_timer.average_time,
+                        train_timer.remain(step, self.max_iter)))
+                    epoch_loss = 0.0
+            if step % self.save_iter == 0:
+                self.log("{} Saving checkpoint file to: {}".format(datetime.datetime.now().strftime("%m/%d %H:%M:%S"),
+                                                                   self.ckpt_dir))
+                save_net(net, "%s-%d" % (self.ckpt_file, step))                       # saver.save(..., global_step=step)
+                np.save(os.path.join(self.loss_dir, str(step) + "map.npy"), val_map)
+        return history
+
+    # the first batch is needed once before the step can be recorded; it is then used as step 1's batch
+    def _feed_peek(self):
+        self._pending = self._feed()
+        return self._pending
+
+    def _next_feed(self):
+        p = getattr(self, "_pending", None)
+        if p is not None:
+            self._pending = None
+            return p
+        return self._feed()

@@ -235,6 +235,12 @@ int disyolo_psroi_assemble(const float* score, const float* detections, int B, i
 int disyolo_mask_paste(const float* masks, int n, int size, const int32_t* rects,
                        const int32_t* classids, int image_h, int image_w, uint8_t* full_masks,
                        uint8_t* merged, void* stream);
+/* image_read of the test / validation drivers (calculate_test_map.py:149-176; utils/val_data.py:36-63):
+ * rgb uint8 [image_h, image_w, 3] (device) -> out f32 [size, size, 3] (device): aspect-preserving
+ * bilinear resize (cv2.resize INTER_LINEAR on the float32 image) centred in the letter box, padding
+ * 127, / 255.  window_host (host, may be NULL) receives the clip window [top, left, bottom, right]. */
+int disyolo_letterbox(const uint8_t* rgb, int image_h, int image_w, float* out, int size,
+                      float* window_host, void* stream);
 /* semantic-segmentation accuracy of evaluate (calculate_test_map.py:303-346): adds the 4x4 pixel
  * confusion counts of two uint8 class maps (0 = background, 1..3 = classes; other values are
  * ignored) to conf int64 [16], conf[true*4 + pred]; the caller zeroes conf before the first image

@@ -851,6 +851,25 @@ def resize_linear(src: np.ndarray, dst_w: int, dst_h: int) -> np.ndarray:
     return (rows[y0, :] * (one - ay)[:, None] + rows[y1, :] * ay[:, None]).astype(np.float32)
 
 
+def image_read(image_rgb: np.ndarray, image_size: int):
+    """calculate_test_map.py:149-176 (= utils/val_data.py:36-63): letter box an RGB uint8 image: resize
+    with cv2.INTER_LINEAR on the float32 image (restated by resize_linear, per channel), centre it on
+    a 127 canvas, divide by 255.0 (float64, as numpy does), return (image f32 [S,S,3], window)."""
+    imgh, imgw = image_rgb.shape[:2]
+    if (float(image_size) / imgw) < (float(image_size) / imgh):
+        imgh = (imgh * image_size) // imgw
+        imgw = image_size
+    else:
+        imgw = (imgw * image_size) // imgh
+        imgh = image_size
+    img = image_rgb.astype(np.float32)
+    small = np.stack([resize_linear(img[:, :, c], imgw, imgh) for c in range(3)], axis=-1)
+    canvas = np.ones((image_size, image_size, 3)) * 127.0
+    top, left = (image_size - imgh) // 2, (image_size - imgw) // 2
+    canvas[top:top + imgh, left:left + imgw, :] = small
+    return (canvas / 255.0).astype(np.float32), letterbox_window(image_rgb.shape[0], image_rgb.shape[1], image_size)
+
+
 def paste_detections(det_box: np.ndarray, det_mask, image_h: int, image_w: int, net_size: int):
     """the per-image body of evaluate (calculate_test_map.py:220-269): every detection's mask is cut
     out of the size x size map at its rounded box, resized to the un-letterboxed box, thresholded at

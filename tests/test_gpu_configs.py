@@ -238,16 +238,22 @@ def test_config2_wire_formats_and_reduce_scatter_variant(dev, one_rank_rccl, wir
     enable_data_parallel(dpn, bucket_mb=4.0, wire=wire, algo=algo)
     plain.build_program(det_thresh=0.1)
     dpn.build_program(det_thresh=0.1)
-    for _ in range(2):
+    # bf16 wire: ONE step (from identical weights); the rounded gradients change the weights in the last
+    # bits, and a second forward pass may then make a different discrete decision (NMS survivor, RoI set)
+    for _ in range(2 if wire == "f32" else 1):
         l0 = float(plain.train_step(None).cpu())
         l1 = float(dpn.train_step(None).cpu())
-        assert l0 == l1 or wire == "bf16"
+        assert l0 == l1
     torch.cuda.synchronize()
     if wire == "f32":
         assert torch.equal(plain.arena, dpn.arena) and torch.equal(plain.adam_v, dpn.adam_v)
     else:
-        assert float((plain.arena - dpn.arena).abs().max()) < 0.5 * cfg.LEARNING_RATE
-        assert rel_l2(dpn.grad_arena, plain.grad_arena) < 2 ** -8
+        dw = (plain.arena - dpn.arena).abs()
+        i = int(dw.argmax())
+        info = "max |dw| %.3g at %d: grads %.6g / %.6g, rel l2 of the gradients %.3g" % (
+            float(dw.max()), i, float(plain.grad_arena[i]), float(dpn.grad_arena[i]), rel_l2(dpn.grad_arena, plain.grad_arena))
+        assert rel_l2(dpn.grad_arena, plain.grad_arena) < 2 ** -8, info
+        assert float(dw.max()) < 0.5 * cfg.LEARNING_RATE, info
 
 
 def test_bf16_gradient_storage_along_the_residual_trunk(dev):
