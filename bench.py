@@ -253,6 +253,10 @@ def main():
     ap.add_argument("--task", default="train", choices=("train", "infer"),
                     help="train = the headline metric; infer = BASELINE.json config 4 (forward + detection filter + "
                          "PS-RoI mask assembly, hipGraph replay), reported as a secondary line")
+    ap.add_argument("--dtype", default="bf16", choices=("bf16", "fp8"),
+                    help="fp8: the locked backbone conv1-52 stores activations and feeds the matrix cores in OCP e4m3 "
+                         "(per-tensor scales calibrated on the first batch); everything trainable stays bf16 "
+                         "(BASELINE.json configs[4]; stage 1 only)")
     ap.add_argument("--repeats", type=int, default=10,
                     help="the timed region of --steps steps is repeated this often; the reported value is the median")
     ap.add_argument("--no-secondary", action="store_true", help="skip the stage-2 / B=32 inference lines of 'secondary'")
@@ -298,12 +302,14 @@ def main():
     B, S = args.batch, args.size
     if args.task == "infer":
         return bench_infer(args, dev, world, rank)
-    net = YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=args.stage, seed=0)
+    net = YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=args.stage, seed=0, dtype=args.dtype)
     if use_dp:
         from disyolo_amd.dp import enable_data_parallel
         enable_data_parallel(net)
     batch = synthetic_batch(B, S, seed=1234 + rank)
     net.set_batch(batch)           # inputs resident in HBM from here on
+    if args.dtype == "fp8":
+        net.calibrate_fp8()        # static per-tensor scales (setup, outside the timed region)
     torch.manual_seed(1234 + rank)
     gen = None                     # default CUDA generator
     if args.autotune == "on":
@@ -362,8 +368,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "repeats": len(regions),
             "ms_per_step_min_max": [round(min(regions) / args.steps * 1e3, 3), round(max(regions) / args.steps * 1e3, 3)],
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "train_step_B%d_%dx%d_3class_stage%d" % (B, S, S, args.stage),
+            "vs_baseline": None,
+            "dtype": "bf16" if args.dtype == "bf16" else "fp8 (e4m3 storage + MFMA operands, conv1-52) / bf16 (trainable layers)",
+            "data": "synthetic",
+            "config": {"workload": "train_step_B%d_%dx%d_3class_stage%d%s" % (B, S, S, args.stage, "" if args.dtype == "bf16" else "_fp8"),
                        "images_per_gpu": B, "global_batch": B * world, "image_size": S,
                        "stage": "1: conv1-52 locked (shipped reference source)" if args.stage == 1 else
                                 "2: all 82 layers trainable",
@@ -409,7 +417,7 @@ def main():
                                "avg_launch_us": round(r["ms_total"] / r["launches"] * 1e3, 2),
                                "launches_per_step": r["launches"] / args.steps}
             out["kernels"] = kernels
-        if world == 1 and not args.no_secondary and args.stage == 1 and B == 8:
+        if world == 1 and not args.no_secondary and args.stage == 1 and B == 8 and args.dtype == "bf16":
             del timer
             out["secondary"] = secondary_measurements(args, dev)
         if world == 1 and not args.no_cpu_baseline:

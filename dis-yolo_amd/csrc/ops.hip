@@ -19,11 +19,12 @@ namespace {
 // ---- conv 1: Cin = 3, k = 3, s = 1, SAME (yolo/yolo3_net_pos.py:159) ---------------
 // Exact f32 FMA (27 taps) per output; 1 thread = 1 pixel x all COUT channels: the 27 input
 // values are loaded once into registers, the weights are wave-uniform scalar loads (SGPR operands).
-template <int COUT>
+// FP8OUT: the output is stored as OCP e4m3 of y * inv_out_scale (32 contiguous bytes per lane, no staging)
+template <int COUT, bool FP8OUT = false>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ img, const float* __restrict__ sw,
                                                          const float* __restrict__ ssc,
                                                          const float* __restrict__ ssh, bf16* __restrict__ y, int B,
-                                                         int H, int W, float alpha) {
+                                                         int H, int W, float alpha, float inv_out_scale = 0.f) {
   // each wave stages its 64 pixels x COUT bf16 in LDS so the global stores are contiguous 1 KiB rows
   __shared__ uint4 stage[4][64 * (COUT / 8)];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -65,10 +66,22 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] = leaky(acc[k] * ssc[cg * 8 + k] + ssh[cg * 8 + k], alpha);
-        // chunk index XOR-swizzled by pixel so the 64 B-strided writes spread over the banks
-        stage[wave][lane * (COUT / 8) + (cg ^ ((lane >> 1) & (COUT / 8 - 1)))] = pack8(acc);
+        if constexpr (FP8OUT) {
+          int lo = 0, hi = 0;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[k] = fminf(fmaxf(acc[k] * inv_out_scale, -448.f), 448.f);
+          lo = __builtin_amdgcn_cvt_pk_fp8_f32(acc[0], acc[1], lo, false);
+          lo = __builtin_amdgcn_cvt_pk_fp8_f32(acc[2], acc[3], lo, true);
+          hi = __builtin_amdgcn_cvt_pk_fp8_f32(acc[4], acc[5], hi, false);
+          hi = __builtin_amdgcn_cvt_pk_fp8_f32(acc[6], acc[7], hi, true);
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(y) + (size_t)m * COUT + cg * 8) = uint2{(unsigned)lo, (unsigned)hi};
+        } else {
+          // chunk index XOR-swizzled by pixel so the 64 B-strided writes spread over the banks
+          stage[wave][lane * (COUT / 8) + (cg ^ ((lane >> 1) & (COUT / 8 - 1)))] = pack8(acc);
+        }
       }
     }
+    if constexpr (FP8OUT) continue;
     // same wave wrote and reads: no block barrier needed, only LDS ordering
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -305,7 +318,22 @@ extern "C" int disyolo_conv_first_fwd(const float* images, const float* w_hwio, 
   int grid = ceil_div(total, 256);
   if (grid > 256 * 16) grid = 256 * 16;
   hipLaunchKernelGGL(conv_first_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, images, w_hwio, scale,
-                     shift, (bf16*)y_bf16, B, H, W, alpha);
+                     shift, (bf16*)y_bf16, B, H, W, alpha, 0.f);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+extern "C" int disyolo_conv_first_fwd_fp8(const float* images, const float* w_hwio, const float* scale,
+                                          const float* shift, void* y_fp8, float out_scale, int B, int H, int W, int Cout,
+                                          float alpha, void* stream) {
+  DY_REQUIRE(images && w_hwio && scale && shift && y_fp8 && B > 0 && H > 0 && W > 0 && out_scale > 0.f, "conv_first_fp8: bad args");
+  DY_REQUIRE(Cout == 32, "conv_first_fp8: Cout must be 32 (got %d)", Cout);
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_conv_first_fwd_fp8(images, w_hwio, scale, shift, y_fp8, out_scale, B, H, W, Cout, alpha, s); });
+  const int64_t total = (int64_t)B * H * W;
+  int grid = ceil_div(total, 256);
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL((conv_first_kernel<32, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, images, w_hwio, scale,
+                     shift, (bf16*)y_fp8, B, H, W, alpha, 1.0f / out_scale);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }

@@ -51,6 +51,12 @@ _SIGS = {
     "disyolo_conv2d_wgrad_workspace": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "disyolo_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_size_t, C.c_void_p]),
+    "disyolo_conv2d_fp8_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                         C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "disyolo_conv_first_fwd_fp8": (C.c_int, [C.c_void_p] * 5 + [C.c_float] + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
+    "disyolo_quant_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "disyolo_dequant_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "disyolo_pack_weights_fp8": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
     "disyolo_conv2d_wgrad_plan": (C.c_int, [C.POINTER(ConvDesc)] + [C.POINTER(C.c_int)] * 4),
     "disyolo_conv_first_wgrad_workspace": (C.c_size_t, [C.c_int] * 4),
     "disyolo_conv_first_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -378,6 +384,43 @@ def conv2d_fwd(d: ConvDesc) -> None:
                                                            "conv2d_fwd"))
         return
     _check(load().disyolo_conv2d_fwd(C.byref(d), _stream()), "conv2d_fwd")
+
+
+def conv2d_fp8_fwd(d: ConvDesc, w8, escale, eshift, y8, out_scale: float, y16=None, residual8=None,
+                   residual_scale: float = 0.0) -> None:
+    """fp8 forward conv: d.x0 = e4m3 input; outputs e4m3 (y8, of y / out_scale) and/or bf16 (y16)"""
+    if TIMER is not None:
+        name = "conv_fp8_kernel<%d,%d,3>" % (128 if d.Cout > 64 else (64 if d.Cout > 32 else 32), 64 if d.C0 % 64 == 0 else 32)
+        TIMER.run(name, conv_flops(d), lambda: _check(load().disyolo_conv2d_fp8_fwd(
+            C.byref(d), _p(w8), _p(escale), _p(eshift), _p(residual8), residual_scale, _p(y8), out_scale, _p(y16), _stream()),
+            "conv2d_fp8_fwd"))
+        return
+    _check(load().disyolo_conv2d_fp8_fwd(C.byref(d), _p(w8), _p(escale), _p(eshift), _p(residual8), residual_scale, _p(y8),
+                                         out_scale, _p(y16), _stream()), "conv2d_fp8_fwd")
+
+
+def conv_first_fwd_fp8(images, w_hwio, scale, shift, y8, out_scale: float, alpha=0.1) -> None:
+    _need(images, torch.float32, "images")
+    _need(y8, torch.uint8, "y8")
+    B, H, W, _ = images.shape
+    _check(load().disyolo_conv_first_fwd_fp8(_p(images), _p(w_hwio), _p(scale), _p(shift), _p(y8), out_scale, B, H, W,
+                                             y8.shape[-1], alpha, _stream()), "conv_first_fwd_fp8")
+
+
+def quant_fp8(x, y8, scale: float) -> None:
+    """y8 (uint8 holding OCP e4m3) = e4m3(x / scale); x bf16 or f32"""
+    if x.dtype not in (torch.bfloat16, torch.float32) or not x.is_contiguous():
+        raise DisyoloError("quant_fp8: x must be contiguous bf16 or f32")
+    _check(load().disyolo_quant_fp8(_p(x), int(x.dtype == torch.float32), _p(y8), x.numel(), scale, _stream()), "quant_fp8")
+
+
+def dequant_fp8(x8, y, scale: float) -> None:
+    _need(y, torch.float32, "y")
+    _check(load().disyolo_dequant_fp8(_p(x8), _p(y), x8.numel(), scale, _stream()), "dequant_fp8")
+
+
+def pack_weights_fp8(w_hwio, w8, ksize, cin, cout, scale: float) -> None:
+    _check(load().disyolo_pack_weights_fp8(_p(w_hwio), _p(w8), ksize, cin, cout, scale, _stream()), "pack_weights_fp8")
 
 
 def conv_first_fwd(images, w_hwio, scale, shift, y, alpha=0.1) -> None:

@@ -32,7 +32,8 @@ class Layer:
     __slots__ = ("idx", "cin", "cout", "k", "stride", "kind", "src", "src_up", "shortcut", "lock", "H", "W", "Ho",
                  "Wo", "w", "bias", "gamma", "beta", "mm", "mv", "scale", "shift", "mean", "rstd", "wp", "wdg", "raw",
                  "act", "stats", "stats_rows", "desc", "grad", "grad_set", "need_grad", "dw", "dbias", "dgamma",
-                 "dbeta", "dx", "pad_t", "pad_l", "dgrad_descs", "wgrad_desc", "cout_pad")
+                 "dbeta", "dx", "pad_t", "pad_l", "dgrad_descs", "wgrad_desc", "cout_pad",
+                 "act8", "w8", "s_w", "s_out", "escale", "desc8", "dual16")
 
     def __init__(self, idx, cin, cout, k, stride, kind, src, src_up=None, shortcut=None):
         self.idx, self.cin, self.cout, self.k, self.stride, self.kind = idx, cin, cout, k, stride, kind
@@ -116,7 +117,7 @@ def var_name(i: int, leaf: str) -> str:
 class YOLONet(object):
     def __init__(self, training: bool = False, device=None, image_size: Optional[int] = None,
                  batch_size: Optional[int] = None, stage: int = 1, lock: Optional[Dict[int, bool]] = None,
-                 seed: int = 0, xavier_locked: bool = True, plan_only: bool = False):
+                 seed: int = 0, xavier_locked: bool = True, plan_only: bool = False, dtype: str = "bf16"):
         # 1. parameters (yolo/yolo3_net_pos.py:15-38)
         self.batchsize = int(batch_size if batch_size is not None else cfg.BATCH_SIZE)
         self.classes = cfg.CLASSES
@@ -133,6 +134,13 @@ class YOLONet(object):
         self.mask_scale = cfg.MASK_SCALE
         self.l2 = cfg.L2_WEIGHT
         self.training = bool(training)
+        # "fp8": the inference-mode layers conv1-52 (the locked backbone of stage 1; every call of an
+        # inference net) keep their activations and MFMA operands in OCP e4m3 with per-tensor scales
+        # (calibrate_fp8()); everything else stays bf16.  BASELINE.json configs[4].
+        if dtype not in ("bf16", "fp8"):
+            raise ValueError("dtype must be 'bf16' or 'fp8'")
+        self.dtype = dtype
+        self.fp8_ready = False
         self.image_size = int(image_size if image_size is not None else cfg.IMAGE_SIZE)
         if self.image_size % 32:
             raise ValueError("image size must be a multiple of 32")
@@ -345,6 +353,8 @@ class YOLONet(object):
             if needs_dgrad:
                 l.wdg = torch.zeros(l.cin, l.k * l.k * l.cout_pad, dtype=BF16, device=dev)
         self._build_descs()
+        if self.dtype == "fp8":
+            self._plan_fp8()
         l1 = self.by_idx[1]
         if self.training and not l1.lock:
             self._img8 = torch.zeros(B, S, S, 8, dtype=BF16, device=dev)
@@ -396,6 +406,55 @@ class YOLONet(object):
         self.ws_det.get(int(max(L.load().disyolo_detect_workspace(B, S, self.num_class), 1 << 20)))
         self._build_dgrad_descs()
         self.refresh_weights()
+
+    # ---- fp8 path of the inference-mode backbone --------------------------------------------
+    FP8_UPTO = 52
+    FP8_DUAL = (4, 9, 26, 43, 52)     # outputs that bf16 layers consume too (skip2..5, the trunk's end)
+
+    def _fp8_layers(self):
+        """layers that run in fp8: conv1..52 when they are in inference mode (locked, or an inference net)"""
+        return [l for l in self.layers if l.idx <= self.FP8_UPTO and (l.lock or not self.training)]
+
+    def _plan_fp8(self) -> None:
+        dev = self.device
+        ls = self._fp8_layers()
+        if [l.idx for l in ls] != list(range(1, self.FP8_UPTO + 1)):
+            raise L.DisyoloError("dtype='fp8' needs conv1-52 in inference mode (stage 1 training, or training=False)")
+        for l in ls:
+            l.act8 = torch.zeros(self.B, l.Ho, l.Wo, l.cout, dtype=torch.uint8, device=dev)
+            l.escale = torch.zeros(l.cout, dtype=F32, device=dev)
+            l.dual16 = l.idx in self.FP8_DUAL
+            l.s_out, l.s_w = 1.0, 1.0
+            if l.idx > 1:
+                l.w8 = torch.zeros(l.cout, l.k * l.k * l.cin, dtype=torch.uint8, device=dev)
+                l.desc8 = L.make_conv_desc(self.by_idx[l.src].act8, l.w8, l.act8, l.k, l.stride, leaky=True, alpha=cfg.ALPHA)
+
+    def calibrate_fp8(self, margin: float = 1.0) -> Dict[int, float]:
+        """Per-tensor scales from the batch currently set: runs conv1-52 in bf16 once, takes max|activation|
+        of every layer (after the residual add) and max|weight|; scale = max / (448 * margin).  Static
+        afterwards (the step can be recorded).  Returns {layer: activation scale}."""
+        if self.dtype != "fp8":
+            raise L.DisyoloError("calibrate_fp8 on a bf16 net")
+        self.fp8_ready = False
+        for l in self._fp8_layers():
+            self._forward_layer(l, False)
+        torch.cuda.synchronize()
+        for l in self._fp8_layers():
+            amax = float(l.act.float().abs().max())
+            l.s_out = max(amax, 1e-12) / (448.0 * margin)
+            if l.idx > 1:
+                l.s_w = max(float(l.w.abs().max()), 1e-12) / 448.0
+        self.fp8_ready = True
+        self.refresh_weights()
+        return {l.idx: l.s_out for l in self._fp8_layers()}
+
+    def _forward_layer_fp8(self, l) -> None:
+        if l.idx == 1:
+            L.conv_first_fwd_fp8(self.images, l.w, l.scale, l.shift, l.act8, l.s_out, alpha=cfg.ALPHA)
+            return
+        sc = self.by_idx[l.shortcut] if l.shortcut is not None else None
+        L.conv2d_fp8_fwd(l.desc8, l.w8, l.escale, l.shift, l.act8, l.s_out, y16=l.act if l.dual16 else None,
+                         residual8=sc.act8 if sc is not None else None, residual_scale=sc.s_out if sc is not None else 0.0)
 
     def _build_descs(self) -> None:
         """conv descriptors (raw pointers into the activation buffers).  Rebuilt when the
@@ -485,6 +544,12 @@ class YOLONet(object):
                 L.pack_weights(l.w, l.wp, l.wdg, l.k, l.cin, l.cout, l.cout_pad)
             if l.kind != "lin":
                 L.bn_fold(l.gamma, l.beta, l.mm, l.mv, cfg.BN_EPSILON, l.scale, l.shift)
+        if self.dtype == "fp8" and self.fp8_ready:
+            for l in self._fp8_layers():
+                if l.idx > 1:
+                    L.pack_weights_fp8(l.w, l.w8, l.k, l.cin, l.cout, l.s_w)
+                    # acc is in units of s_in * s_w: fold them into the batch-norm scale
+                    torch.mul(l.scale, self.by_idx[l.src].s_out * l.s_w, out=l.escale)
 
     # ------------------------------------------------------------------ forward
     # layers that only feed a detection head: in a recorded step they run on the side lane while
@@ -510,6 +575,9 @@ class YOLONet(object):
 
     def _forward_layer(self, l, is_training: bool) -> None:
         B = self.B
+        if self.dtype == "fp8" and self.fp8_ready and l.act8 is not None:
+            self._forward_layer_fp8(l)
+            return
         train_bn = is_training and self.training and (not l.lock) and l.kind != "lin"
         M = B * l.Ho * l.Wo
         res = self.by_idx[l.shortcut].act if l.shortcut is not None else None

@@ -103,6 +103,28 @@ size_t disyolo_conv2d_wgrad_workspace(const disyolo_conv_desc* d);
 int disyolo_conv2d_wgrad(const disyolo_conv_desc* d, const void* dy, int dy_ld, float* dw,
                          void* workspace, size_t workspace_bytes, void* stream);
 /* same for the first layer (f32 image input, Cin = 3): dw f32 [3,3,3,Cout] */
+/* ---- fp8 (OCP e4m3) forward path of the inference-mode layers (BASELINE.json configs[4]; the reference
+ * is f32: yolo/yolo3_net_pos.py:132-146 conv_bn with lock=True) ----
+ * y = leaky(acc * escale[c] + eshift[c]) [+ residual_fp8 * residual_scale], acc = sum of e4m3 products in
+ * f32 (v_mfma_f32_16x16x32_fp8_fp8).  desc: x0 = e4m3 NHWC input, geometry / alpha / LEAKY flag as for
+ * conv2d_fwd (w, scale, shift, residual, y of the descriptor are ignored); w_fp8 = e4m3 [Cout][k*k*Cin]
+ * (pack_weights_fp8); escale = s_in * s_w * folded-BN scale, eshift = folded-BN shift (f32 [Cout]).
+ * Outputs: y_fp8 = e4m3 of y / out_scale and/or y_bf16 = bf16 of y (either may be NULL).
+ * Cin a power of two >= 32, Cout a multiple of 16, no fused concat. */
+int disyolo_conv2d_fp8_fwd(const disyolo_conv_desc* d, const void* w_fp8, const float* escale,
+                           const float* eshift, const void* residual_fp8, float residual_scale,
+                           void* y_fp8, float out_scale, void* y_bf16, void* stream);
+/* first layer (f32 image, exact f32 FMA, folded BN + leaky) with the output stored as e4m3 of y / out_scale */
+int disyolo_conv_first_fwd_fp8(const float* images, const float* w_hwio, const float* scale, const float* shift,
+                               void* y_fp8, float out_scale, int B, int H, int W, int Cout, float alpha,
+                               void* stream);
+/* e4m3 of x / scale (x bf16, or f32 when x_is_f32; n % 8 == 0, saturating at +-448); back to f32 * scale */
+int disyolo_quant_fp8(const void* x, int x_is_f32, void* y_fp8, int64_t n, float scale, void* stream);
+int disyolo_dequant_fp8(const void* x_fp8, float* y, int64_t n, float scale, void* stream);
+/* HWIO f32 weights -> e4m3 [Cout][k*k*Cin] of w / scale */
+int disyolo_pack_weights_fp8(const float* w_hwio, void* w_fp8, int ksize, int Cin, int Cout,
+                             float scale, void* stream);
+
 /* which kernel the launcher picks for this descriptor: kind 0 = im2col kernel (tile_n = channel tile),
  * 1 = tap-fused 3x3 kernel (tile_n = channel tile, ring = input ring slots); splits = pixel splits
  * (f32 slabs summed by slab_reduce when > 1).  desc.tile bit 0x100 forces the im2col kernel; bits

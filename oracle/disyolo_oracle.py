@@ -213,6 +213,14 @@ def bf16_ste(t: torch.Tensor) -> torch.Tensor:
     return t + (t.detach().to(torch.bfloat16).to(t.dtype) - t.detach())
 
 
+def fp8_e4m3(t: torch.Tensor, scale: float) -> torch.Tensor:
+    """values representable as OCP e4m3 * scale: saturate to +-448, round to nearest even (torch's
+    float8_e4m3fn conversion).  NOT part of the reference (f32 throughout): emulation of the port's fp8
+    storage format for the parity tests of BASELINE.json configs[4]."""
+    q = (t.detach().float() / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() * scale
+    return q.to(t.dtype)
+
+
 def _q(quant, t):
     return t if quant is None else quant(t)
 
@@ -268,7 +276,7 @@ def upsample2(x: torch.Tensor) -> torch.Tensor:
 def build_network(params: Dict[str, torch.Tensor], images: torch.Tensor, is_training: bool,
                   lock: Dict[int, bool], updates: Optional[Dict[str, torch.Tensor]] = None,
                   taps: Optional[Dict[str, torch.Tensor]] = None, quant=None,
-                  force: Optional[Dict[str, torch.Tensor]] = None):
+                  force: Optional[Dict[str, torch.Tensor]] = None, fp8: Optional[Dict] = None):
     """yolo/yolo3_net_pos.py:153-463 (the active m=1/2 mask subnet, :380-412).
 
     Returns (yolos=[yolov3_3, yolov3_2, yolov3_1] each [B,g,g,3,5+C], mask_pos
@@ -281,15 +289,27 @@ def build_network(params: Dict[str, torch.Tensor], images: torch.Tensor, is_trai
     of a randomly initialised network.
     """
     sp = layer_specs()
+    # fp8 = {"upto": 52, "s_out": {layer: scale}, "s_w": {layer: scale}}: emulation of the port's e4m3 path --
+    # layers 1..upto (inference mode) store their output as e4m3 * s_out and use e4m3 * s_w weights; the
+    # outputs the bf16 layers consume too (skip2..5, act52) are ALSO kept as bf16 of the unquantised value
+    dual = {}
 
     def cb(x, i):
+        if fp8 is not None and 2 <= i <= fp8["upto"]:
+            p8 = dict(params)
+            p8[_name(i, "weights")] = fp8_e4m3(params[_name(i, "weights")], fp8["s_w"][i])
+            return conv_bn(x, p8, i, sp[i][3], lock[i], is_training, updates, quant=None)
         y = conv_bn(x, params, i, sp[i][3], lock[i], is_training, updates, quant=quant)
         return y
 
     def tap(name, t):
         # every stored activation is rounded once, after the residual add (bf16 path);
         # head logits / score maps stay f32
-        if quant is not None and name not in ("act59", "act67", "act75", "act82"):
+        idx = int(name[3:])
+        if fp8 is not None and idx <= fp8["upto"]:
+            dual[name] = quant(t) if quant is not None else t
+            t = fp8_e4m3(t, fp8["s_out"][idx])
+        elif quant is not None and name not in ("act59", "act67", "act75", "act82"):
             t = quant(t)
         if taps is not None:
             taps[name] = t
@@ -309,9 +329,10 @@ def build_network(params: Dict[str, torch.Tensor], images: torch.Tensor, is_trai
             net = tap("act%d" % (i + 1), cb(net, i + 1) + shortcut)      # res add after act (:148-151)
             i += 2
         if skipname:
-            skips[skipname] = net
+            skips[skipname] = dual.get("act%d" % (i - 1), net)
             net = tap("act%d" % down, cb(net, down))
             i = down + 1
+    net = dual.get("act52", net)
     # head 1 (:258-281)
     for i in (53, 54, 55, 56, 57):
         net = tap("act%d" % i, cb(net, i))

@@ -1,0 +1,175 @@
+"""The fp8 (OCP e4m3) forward path of the inference-mode backbone -- BASELINE.json configs[4].
+
+The reference has no counterpart (f32 throughout, yolo/yolo3_net_pos.py:42-57): what is checked is that the
+kernels compute the reference's conv_bn / res_conv_bn (:132-151) on e4m3 operands exactly as the oracle's
+e4m3 emulation (torch.float8_e4m3fn rounding) does, and how far the fp8 network is from the bf16 one."""
+import numpy as np
+import pytest
+import torch
+
+import disyolo_oracle as O
+from disyolo_amd import lib as L
+from disyolo_amd.net import YOLONet
+
+pytestmark = pytest.mark.gpu
+
+
+def e4m3_bytes(x: torch.Tensor) -> torch.Tensor:
+    return x.float().clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+def e4m3_values(b: torch.Tensor) -> torch.Tensor:
+    return b.view(torch.float8_e4m3fn).float()
+
+
+def test_quantiser_is_ocp_e4m3_with_saturation_and_ties_to_even(dev):
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.randn(4096, generator=g) * 50, torch.randn(4096, generator=g) * 0.01,
+                   torch.tensor([0.0, -0.0, 448.0, -448.0, 449.0, 1e6, -1e6, 2 ** -9, 2 ** -10, 1.5 * 2 ** -9,
+                                 17.0, 18.0, 19.0, 21.0, 23.0, 0.0009765625 * 3]),      # ties between e4m3 codes
+                   torch.arange(-448, 449, 1.0)])
+    x = x[: x.numel() // 8 * 8].contiguous()
+    for scale in (1.0, 0.37):
+        y = torch.zeros(x.numel(), dtype=torch.uint8, device=dev)
+        L.quant_fp8(x.to(dev), y, scale)
+        want = e4m3_bytes(x / scale)
+        torch.cuda.synchronize()
+        got = y.cpu()
+        # -0.0 / +0.0 may differ in sign only
+        diff = (got != want) & ~((got & 0x7F == 0) & (want & 0x7F == 0))
+        assert int(diff.sum()) == 0, (x[diff][:8], got[diff][:8], want[diff][:8])
+        back = torch.zeros(x.numel(), dtype=torch.float32, device=dev)
+        L.dequant_fp8(y, back, scale)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(back.cpu().numpy(), (e4m3_values(got) * scale).numpy())
+    assert float(e4m3_values(e4m3_bytes(torch.tensor([1e6])))) == 448.0        # no inf / nan in e4m3fn: saturate
+
+
+CASES = [  # B, H, W, Cin, Cout, k, stride, residual, dual
+    (2, 18, 18, 64, 128, 3, 1, True, True),       # BN 128, BK 64
+    (1, 36, 36, 32, 64, 3, 2, False, False),      # Cin 32 -> BK 32, stride 2 asymmetric SAME pad, BN 64
+    (2, 12, 12, 64, 32, 1, 1, False, True),       # BN 32
+    (1, 20, 24, 128, 256, 1, 1, False, False),    # two channel tiles, ragged M
+    (3, 9, 7, 256, 48, 3, 1, True, False),        # Cout not a multiple of the tile, odd sizes
+    (1, 72, 72, 32, 32, 3, 1, False, False),      # BN 32, BK 32
+    (1, 128, 128, 64, 256, 1, 1, False, True),    # a full grid of 128 x 128 tiles (the small maps above use 64-pixel tiles)
+    (1, 96, 96, 64, 128, 3, 1, True, False),      # 128 x 128 tiles, 3x3, residual
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,res,dual", CASES)
+def test_conv_fp8_matches_f64_on_e4m3_operands(dev, B, H, W, Cin, Cout, k, s, res, dual):
+    g = torch.Generator().manual_seed(B * 1000 + H + Cin + Cout + k)
+    s_in, s_w, s_out, s_res = 0.05, 0.002, 0.11, 0.07
+    x8 = e4m3_bytes(torch.randn(B, H, W, Cin, generator=g) / s_in * 1.5)
+    w = torch.randn(k, k, Cin, Cout, generator=g) / (k * k * Cin) ** 0.5
+    bscale = torch.rand(Cout, generator=g) + 0.5
+    bshift = torch.randn(Cout, generator=g) * 0.3
+    w8 = torch.zeros(Cout, k * k * Cin, dtype=torch.uint8, device=dev)
+    L.pack_weights_fp8(w.to(dev), w8, k, Cin, Cout, s_w)
+    torch.cuda.synchronize()
+    wq = e4m3_values(e4m3_bytes(w / s_w)) * s_w                                   # what the packer must have stored
+    np.testing.assert_array_equal(e4m3_values(w8.cpu()).reshape(Cout, k, k, Cin).permute(1, 2, 3, 0).numpy() * np.float32(s_w),
+                                  wq.numpy())
+    xd = (e4m3_values(x8) * s_in).double()
+    y = O.conv2d_same(xd, wq.double(), s) * bscale.double() + bshift.double()
+    y = O.leaky_relu(y, 0.1)
+    Ho, Wo = y.shape[1], y.shape[2]
+    r8 = None
+    if res:
+        r8 = e4m3_bytes(torch.randn(B, Ho, Wo, Cout, generator=g) / s_res)
+        y = y + (e4m3_values(r8) * s_res).double()
+    x8d = x8.to(dev)
+    y8 = torch.zeros(B, Ho, Wo, Cout, dtype=torch.uint8, device=dev)
+    y16 = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=dev) if dual else None
+    d = L.make_conv_desc(x8d, w8, y8, k, s, leaky=True, alpha=0.1)
+    escale = (bscale * (s_in * s_w)).to(dev)
+    L.conv2d_fp8_fwd(d, w8, escale, bshift.to(dev), y8, s_out, y16=y16, residual8=None if r8 is None else r8.to(dev),
+                     residual_scale=s_res if res else 0.0)
+    torch.cuda.synchronize()
+    want8 = e4m3_bytes(y / s_out)
+    got8 = y8.cpu()
+    same = (got8 == want8) | ((got8 & 0x7F == 0) & (want8 & 0x7F == 0))
+    frac = float(same.float().mean())
+    # f32 accumulation order can move a value across an e4m3 rounding boundary: rare, and then by one code
+    assert frac > 0.995, "only %.4f of the e4m3 outputs equal the rounded f64 result" % frac
+    gv, wv = e4m3_values(got8), e4m3_values(want8)
+    assert float(((gv - wv).abs() / wv.abs().clamp(min=2 ** -6)).max()) <= 0.1251
+    if dual:
+        err = (y16.float().cpu().double() - y).abs()
+        assert bool((err <= 2.0 ** -7 * y.abs() + 1e-3).all())
+
+
+def _heads(net, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for i in (59, 67, 75, 82):
+            net.params["yolo/convolutional%d/weights" % i].mul_(6.0)
+            b = net.params["yolo/convolutional%d/biases" % i]
+            b.copy_((torch.randn(b.shape, generator=g) * 0.5).to(b.device))
+    net.refresh_weights()
+
+
+def rel(got, want):
+    got, want = torch.as_tensor(got).double().cpu().flatten(), torch.as_tensor(want).double().cpu().flatten()
+    return float((got - want).norm() / (want.norm() + 1e-30))
+
+
+def test_fp8_inference_forward_matches_the_e4m3_emulating_oracle(dev):
+    B, S = 2, 192
+    b = O.synthetic_batch(B, S, seed=7)
+    net = YOLONet(training=False, device=dev, image_size=S, batch_size=B, stage=1, seed=0, dtype="fp8")
+    ref = YOLONet(training=False, device=dev, image_size=S, batch_size=B, stage=1, seed=0)
+    _heads(net, 3)
+    _heads(ref, 3)
+    net._set_inputs(b["images"], b["clip_window"])
+    s_out = net.calibrate_fp8()
+    assert len(s_out) == 52 and all(v > 0 for v in s_out.values())
+    preds, det, mask_pos = net.forward(b["images"], b["clip_window"], [0.1], is_training=False)
+    torch.cuda.synchronize()
+    p = {k: v.detach().cpu().float() for k, v in net.params.items()}
+    fp8 = {"upto": 52, "s_out": s_out, "s_w": {l.idx: l.s_w for l in net.layers if l.idx <= 52 and l.idx > 1}}
+    taps = {}
+    yq, mq = O.build_network(p, b["images"], False, O.default_lock(1), quant=O.bf16_ste, fp8=fp8, taps=taps)
+    # per layer of the free-running fp8 chain: dequantised device activations vs the emulation.  One e4m3 code
+    # is 6-12 % of a value; an f32 summation-order difference flips a rounding now and then and the flips
+    # propagate, so the distance grows slowly with depth (measured: 0.5 % at conv2, ~4 % at conv10-52)
+    worst = 0.0
+    for l in net.layers[:52]:
+        got = torch.zeros(l.act8.numel(), device=dev)
+        L.dequant_fp8(l.act8, got, l.s_out)
+        r = rel(got.view(l.act8.shape), taps["act%d" % l.idx])
+        worst = max(worst, r)
+        assert r < 0.15, "fp8 layer %d: rel l2 %.3g" % (l.idx, r)
+    for got, want in list(zip(preds, yq)) + [(mask_pos, mq)]:
+        assert rel(got, want) < 0.2
+    # distance of the fp8 network from the bf16 one (the accuracy price of the format), recorded in DESIGN.md
+    preds_b, _, mask_b = ref.forward(b["images"], b["clip_window"], [0.1], is_training=False)
+    torch.cuda.synchronize()
+    gap = max(rel(a, c) for a, c in list(zip(preds, preds_b)) + [(mask_pos, mask_b)])
+    import json, os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump({"worst_layer_rel_l2_vs_e4m3_oracle": worst, "outputs_rel_l2_vs_bf16_network": gap,
+               "outputs_rel_l2_vs_e4m3_oracle": max(rel(a, c) for a, c in list(zip(preds, yq)) + [(mask_pos, mq)])},
+              open(os.path.join(out, "fp8_accuracy.json"), "w"), indent=1)
+    assert gap < 0.35, gap
+
+
+def test_fp8_backbone_training_step_records_and_replays_bit_identically(dev):
+    B, S = 2, 64
+    b = O.synthetic_batch(B, S, seed=23)
+    nets = [YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=1, seed=4, dtype="fp8") for _ in range(2)]
+    for n in nets:
+        _heads(n, 5)
+        n.shuffle_seed = 2
+        n.set_batch(b)
+        n.calibrate_fp8()
+    nets[1].build_program(det_thresh=0.1)
+    l0 = [float(nets[0].train_step(None, det_thresh=0.1).cpu()) for _ in range(3)]
+    l1 = [float(nets[1].train_step(None).cpu()) for _ in range(3)]
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(l0, l1)
+    assert torch.equal(nets[0].arena, nets[1].arena) and np.isfinite(l0).sum() >= 2
+    # the trainable layers really consumed the fp8 backbone's bf16 hand-over (skip / trunk outputs)
+    assert float(nets[0].by_idx[52].act.float().abs().max()) > 0 and float(nets[0].by_idx[26].act.float().abs().max()) > 0
