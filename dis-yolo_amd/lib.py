@@ -114,6 +114,12 @@ _SIGS = {
     "disyolo_cmdlist_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "disyolo_cmdlist_run_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "disyolo_cmdlist_side_stream": (C.c_void_p, [C.c_void_p]),
+    "disyolo_polygon_mask": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p]),
+    "disyolo_aug_place": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
+    "disyolo_aug_salt_pepper": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "disyolo_aug_change_light": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
+    "disyolo_aug_motion_blur3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "disyolo_aug_to_float": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "disyolo_crc32c": (C.c_uint32, [C.c_void_p, C.c_size_t, C.c_uint32]),
     "disyolo_l2_workspace": (C.c_size_t, [C.c_int64]),
     "disyolo_l2_loss": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -566,6 +572,41 @@ def letterbox(rgb_u8, out, size: int):
     _check(load().disyolo_letterbox(_p(rgb_u8), int(rgb_u8.shape[0]), int(rgb_u8.shape[1]), _p(out), size, win, _stream()),
            "letterbox")
     return np.array(list(win), np.float32)
+
+
+def polygon_mask(px, py, poly_start, poly_is_out, image_h: int, image_w: int, mask) -> None:
+    """px/py f32 CUDA [nv]; poly_start int32 CUDA [npoly+1]; poly_is_out int32 CUDA [npoly]; mask uint8 CUDA [H,W]"""
+    _need(px, torch.float32, "px")
+    _need(py, torch.float32, "py")
+    _need(poly_start, torch.int32, "poly_start")
+    _need(poly_is_out, torch.int32, "poly_is_out")
+    _need(mask, torch.uint8, "mask")
+    _check(load().disyolo_polygon_mask(_p(px), _p(py), _p(poly_start), _p(poly_is_out), int(poly_is_out.numel()), image_h,
+                                       image_w, _p(mask), _stream()), "polygon_mask")
+
+
+def aug_place(src, is_mask: bool, dst, size: int, new_w: int, new_h: int, dx: int, dy: int, flip: int) -> None:
+    _need(src, torch.uint8, "src")
+    _need(dst, torch.uint8, "dst")
+    _check(load().disyolo_aug_place(_p(src), int(is_mask), int(src.shape[0]), int(src.shape[1]), _p(dst), size, new_w, new_h,
+                                    dx, dy, flip, _stream()), "aug_place")
+
+
+def aug_salt_pepper(image, size: int, rows, cols, nsalt: int, npepper: int) -> None:
+    _check(load().disyolo_aug_salt_pepper(_p(image), size, _p(rows), _p(cols), nsalt, npepper, _stream()), "aug_salt_pepper")
+
+
+def aug_change_light(image, size: int, coeff: float) -> None:
+    _check(load().disyolo_aug_change_light(_p(image), size, float(coeff), _stream()), "aug_change_light")
+
+
+def aug_motion_blur3(src, dst, size: int, angle: int, line_type: int) -> None:
+    _check(load().disyolo_aug_motion_blur3(_p(src), _p(dst), size, angle, line_type, _stream()), "aug_motion_blur3")
+
+
+def aug_to_float(image, out) -> None:
+    _need(out, torch.float32, "out")
+    _check(load().disyolo_aug_to_float(_p(image), _p(out), image.numel(), _stream()), "aug_to_float")
 
 
 def confusion16(true_map, pred_map, conf) -> None:

@@ -1,0 +1,214 @@
+"""Training data pipeline: the counterpart of ``utils/train_data.py`` (``defect_train`` :18-531).
+
+``defect_train.get()`` of the reference builds every batch on the host, synchronously, with cv2 and
+scikit-image (:44-276) -- decode, rasterise the annotation polygons, random scale / crop, flip, motion blur /
+noise / light change, YOLO target assignment.  At the step rates of the HIP path that loader would be three
+orders of magnitude too slow, so here the HOST only draws the random decisions (in the
+reference's order, from an injectable ``numpy.random.RandomState``), transforms the handful of boxes and
+assigns the targets, and the GPU does all pixel work (``csrc/augment.hip``): polygon rasterisation, bilinear
+resize + place + pad + flip of image and masks, the three photometric augmentations, /255 -- straight into the
+batch buffers ``YOLONet.set_batch`` consumes.
+
+Same ``get()`` contract: (images [B,S,S,3] f32, true_masks [B,20,S,S] bool, true_boxes [B,1,1,1,20,5],
+yolo_3, yolo_2, yolo_1, clip_window [B,4]); tensors live on the GPU (``.cpu().numpy()`` for a host caller).
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import config as cfg
+from . import lib as L
+from .synth import assign_targets
+
+
+def rasterize_instance(polys: Sequence[Dict], image_h: int, image_w: int, device, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``load_mask`` for one instance (utils/train_data.py:325-336) on the GPU: polys = [{'type': 'out'|'in',
+    'all_points_x': [...], 'all_points_y': [...]}] -> uint8 CUDA [image_h, image_w]"""
+    xs = np.concatenate([np.asarray(p["all_points_x"], np.float32) for p in polys]) if polys else np.zeros(0, np.float32)
+    ys = np.concatenate([np.asarray(p["all_points_y"], np.float32) for p in polys]) if polys else np.zeros(0, np.float32)
+    start = np.cumsum([0] + [len(p["all_points_x"]) for p in polys]).astype(np.int32)
+    is_out = np.asarray([1 if p["type"] == "out" else 0 for p in polys], np.int32)
+    if out is None:
+        out = torch.empty(image_h, image_w, dtype=torch.uint8, device=device)
+    if len(polys) == 0:
+        out.zero_()
+        return out
+    L.polygon_mask(torch.from_numpy(xs).to(device), torch.from_numpy(ys).to(device), torch.from_numpy(start).to(device),
+                   torch.from_numpy(is_out).to(device), image_h, image_w, out)
+    return out
+
+
+def extract_bboxes(mask: torch.Tensor):
+    """utils/train_data.py:357-373: x1, y1, x2, y2 with x2 / y2 one past the last set pixel"""
+    cols = torch.nonzero(mask.any(dim=0)).flatten()
+    rows = torch.nonzero(mask.any(dim=1)).flatten()
+    return int(cols[0]), int(rows[0]), int(cols[-1]) + 1, int(rows[-1]) + 1
+
+
+class defect_train(object):
+    """labels: [{'image': RGB uint8 array [H,W,3] (or 'imname': path decoded with PIL), 'class_names': [...],
+    'polygons': [[{'type', 'all_points_x', 'all_points_y'}, ...] per instance]}] -- the ``gt_labels`` structure of
+    the reference's cache (utils/train_data.py:278-319)."""
+
+    def __init__(self, labels: List[Dict], batch_size: Optional[int] = None, image_size: Optional[int] = None, device=None,
+                 rng: Optional[np.random.RandomState] = None, flipped: Optional[bool] = None,
+                 blur_noise_light: Optional[bool] = None):
+        self.batch_size = cfg.BATCH_SIZE if batch_size is None else batch_size
+        self.image_size = cfg.IMAGE_SIZE if image_size is None else image_size
+        self.base_grid = self.image_size // 32
+        self.max_box_per_image = cfg.MAX_BOX_PER_IMAGE
+        self.anchors = cfg.ANCHORS
+        self.num_anchor = 3
+        self.num_class = len(cfg.CLASSES)
+        self.class_to_ind = dict(zip(cfg.CLASSES, range(self.num_class)))
+        self.flipped = cfg.FLIPPED if flipped is None else flipped
+        self.blur_noise_light = cfg.BLUR_NOISE_LIGHT if blur_noise_light is None else blur_noise_light
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.rng = rng if rng is not None else np.random.RandomState()
+        self.cursor, self.epoch = 0, 1
+        self.gt_labels = list(labels)
+        self.rng.shuffle(self.gt_labels)                       # :40
+        self.random_labels = copy.copy(self.gt_labels)
+        B, S, G = self.batch_size, self.image_size, self.max_box_per_image
+        dev = self.device
+        # batch buffers, written in place by the kernels
+        self.images = torch.zeros(B, S, S, 3, dtype=torch.float32, device=dev)
+        self.true_masks = torch.zeros(B, G, S, S, dtype=torch.uint8, device=dev)
+        self._frame = [torch.zeros(S, S, 3, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.last_decisions: List[Dict] = []                   # the random draws of the last get(), for tests / logging
+
+    def _image(self, label) -> np.ndarray:
+        if "image" in label:
+            return np.asarray(label["image"], np.uint8)
+        from .evaluate import load_image_rgb
+        return load_image_rgb(label["imname"])
+
+    def get(self):
+        B, S, G, rng = self.batch_size, self.image_size, self.max_box_per_image, self.rng
+        dev = self.device
+        window = np.zeros((B, 4), np.float32)
+        window[:, :] = [0.0, 0.0, 1.0, 1.0]
+        true_boxes = np.zeros((B, 1, 1, 1, G, 5), np.float32)
+        g1 = self.base_grid
+        ys = [np.zeros((B, g, g, 3, 5 + self.num_class), np.float32) for g in (4 * g1, 2 * g1, g1)]   # yolo3, yolo2, yolo1
+        self.true_masks.zero_()
+        self.last_decisions = []
+        for count in range(B):
+            label = self.random_labels[self.cursor]
+            image = self._image(label)
+            image_h, image_w = image.shape[:2]
+            polygons, class_names = label["polygons"][:G], label["class_names"][:G]           # :77-81
+            masks = [rasterize_instance(p, image_h, image_w, dev) for p in polygons]          # load_mask
+            keep = [i for i, m in enumerate(masks) if bool(m.any())]                          # load_box: non-empty masks
+            assert len(keep) == len(class_names), "an annotated instance rasterised to nothing"
+            boxes = np.array([extract_bboxes(masks[i]) for i in keep], np.float32).reshape(-1, 4)
+            cls = [self.class_to_ind[class_names[i]] for i in keep]
+            # ---- augmentation step 1: random scale and crop (:90-133); the draws happen in the reference's order
+            net_w = net_h = S
+            scale_crop = int(rng.randint(low=1, high=3))
+            if scale_crop == 2:
+                jitter = 0.2
+                new_ar = image_w / image_h * rng.uniform(1 - jitter, 1 + jitter) / rng.uniform(1 - jitter, 1 + jitter)
+                scale = rng.uniform(0.75, 1.5)
+                if new_ar < 1:
+                    new_h = int(scale * net_h)
+                    new_w = int(new_h * new_ar)
+                else:
+                    new_w = int(scale * net_w)
+                    new_h = int(new_w / new_ar)
+                dx = int(rng.uniform(0, net_w - new_w))
+                dy = int(rng.uniform(0, net_h - new_h))
+                sx, sy = float(new_w) / image_w, float(new_h) / image_h
+                if len(boxes):
+                    x1, y1 = boxes[:, 0] * sx + dx, boxes[:, 1] * sy + dy
+                    x2, y2 = boxes[:, 2] * sx + dx, boxes[:, 3] * sy + dy
+                    if x1.min() < 0 or y1.min() < 0 or x2.max() >= net_w or y2.max() >= net_h:
+                        scale_crop = 1                                                     # keep every defect inside
+            if scale_crop == 1:
+                new_ar = image_w / image_h
+                if new_ar < 1:
+                    new_h = int(1.0 * net_h)
+                    new_w = int(new_h * new_ar)
+                else:
+                    new_w = int(1.0 * net_w)
+                    new_h = int(new_w / new_ar)
+                dx, dy = (net_w - new_w) // 2, (net_h - new_h) // 2
+                sx, sy = float(new_w) / image_w, float(new_h) / image_h
+            # ---- boxes into the net frame (:136-147) and the three YOLO target grids (:149-178)
+            bx = np.zeros((len(boxes), 4), np.float32)
+            for j, (x1, y1, x2, y2) in enumerate(boxes):
+                x1 = max(min(float(x1) * sx + dx, net_w - 1), 0)
+                y1 = max(min(float(y1) * sy + dy, net_h - 1), 0)
+                x2 = max(min(float(x2) * sx + dx, net_w - 1), 0)
+                y2 = max(min(float(y2) * sy + dy, net_h - 1), 0)
+                bx[j] = [(x2 + x1) / 2.0, (y2 + y1) / 2.0, x2 - x1, y2 - y1]
+            grids = assign_targets(bx, cls, S, self.num_class)                               # pixel units, like the reference here
+            # ---- step 2: flip (:187-226) -- the grids are mirrored and the stored centres reflected
+            flip = 1
+            if self.flipped:
+                flip = int(rng.randint(low=1, high=4))
+            if flip == 2:
+                bx[:, 0] = net_w - 1 - bx[:, 0]
+                grids = [g[:, ::-1].copy() for g in grids]
+                for g in grids:
+                    obj = g[..., 4] == 1
+                    g[..., 0][obj] = net_w - 1 - g[..., 0][obj]
+            elif flip == 3:
+                bx[:, 1] = net_h - 1 - bx[:, 1]
+                grids = [g[::-1].copy() for g in grids]
+                for g in grids:
+                    obj = g[..., 4] == 1
+                    g[..., 1][obj] = net_h - 1 - g[..., 1][obj]
+            # ---- step 3: blur / noise / light (:228-241)
+            bnl = 1
+            if self.blur_noise_light:
+                bnl = int(rng.randint(low=1, high=5))
+            dec = {"scale_crop": scale_crop, "new_w": new_w, "new_h": new_h, "dx": dx, "dy": dy, "flip": flip, "bnl": bnl}
+            # ---- pixels (image_read :376-416, resize_mask :418-444) on the GPU
+            src = torch.from_numpy(np.ascontiguousarray(image)).to(dev)
+            f0, f1 = self._frame
+            L.aug_place(src, False, f0, S, new_w, new_h, dx, dy, flip)
+            if bnl == 2:                                                                    # salt & pepper (:511-525)
+                n_el = S * S * 3
+                ns, npp = int(math.ceil(0.004 * n_el * 0.2)), int(math.ceil(0.004 * n_el * 0.8))
+                cs = [rng.randint(0, i - 1, ns) for i in (S, S, 3)]
+                cp = [rng.randint(0, i - 1, npp) for i in (S, S, 3)]
+                rows = torch.from_numpy(np.concatenate([cs[0], cp[0]]).astype(np.int32)).to(dev)
+                cols = torch.from_numpy(np.concatenate([cs[1], cp[1]]).astype(np.int32)).to(dev)
+                L.aug_salt_pepper(f0, S, rows, cols, ns, npp)
+                dec.update(salt=(cs[0], cs[1]), pepper=(cp[0], cp[1]))
+            elif bnl == 3:                                                                  # light (:527-535)
+                coeff = rng.uniform() + 0.5
+                L.aug_change_light(f0, S, coeff)
+                dec["coeff"] = coeff
+            elif bnl == 4:                                                                  # motion blur (:466-494)
+                length_idx = rng.randint(0, 1)                                              # lineLengths = [3]
+                type_idx = int(rng.randint(0, 3))                                           # right, left, full
+                angles = np.linspace(0, 180, 4, endpoint=False)                             # kernel centre 1 -> 4 lines
+                angle = int(angles[rng.randint(0, len(angles))])
+                L.aug_motion_blur3(f0, f1, S, angle, {0: 1, 1: 2, 2: 0}[type_idx])
+                f0 = f1
+                dec.update(angle=angle, line_type=("right", "left", "full")[type_idx], _len=int(length_idx))
+            L.aug_to_float(f0, self.images[count])
+            for j, i in enumerate(keep):
+                L.aug_place(masks[i], True, self.true_masks[count, j], S, new_w, new_h, dx, dy, flip)
+            # ---- normalise (:250-257)
+            true_boxes[count, 0, 0, 0, :len(bx), :4] = bx / S
+            true_boxes[count, 0, 0, 0, :len(bx), 4] = cls
+            for dst, g in zip(ys, grids):
+                g = g.copy()
+                g[..., 0:4] = g[..., 0:4] / S
+                dst[count] = g
+            self.last_decisions.append(dec)
+            self.cursor += 1
+            if self.cursor >= len(self.gt_labels):                                          # :266-271
+                self.rng.shuffle(self.gt_labels)
+                self.random_labels = copy.copy(self.gt_labels)
+                self.cursor = 0
+                self.epoch += 1
+        return (self.images, self.true_masks.bool(), true_boxes, ys[0], ys[1], ys[2], window)

@@ -300,6 +300,29 @@ int disyolo_l2_loss(const float* w, int64_t n, float l2, float* out, void* works
  * shortcuts (yolo/yolo3_net_pos.py:150) */
 int disyolo_add_bf16(const void* src, void* dst, int64_t n, int accumulate, void* stream);
 
+/* ---- training-data pipeline (utils/train_data.py:44-276, 321-531): the pixel work of defect_train.get() ----
+ * polygon_mask: one annotated instance = npoly polygons (vertices px/py f32, polygon k = [poly_start[k],
+ * poly_start[k+1]), poly_is_out[k] = 1 'out' / 0 'in' = hole) -> uint8 mask [image_h, image_w]:
+ * skimage.draw.polygon per polygon in order, holes cleared, vertex pixels set (load_mask, :321-338). */
+int disyolo_polygon_mask(const float* px, const float* py, const int32_t* poly_start,
+                         const int32_t* poly_is_out, int npoly, int image_h, int image_w, uint8_t* mask,
+                         void* stream);
+/* apply_random_scale_and_crop + flip (:392-397, 428-434, 446-464): src resized to new_w x new_h (cv2
+ * INTER_LINEAR), placed with its corner at (dx, dy) of the size x size frame (negative = cropped),
+ * flip 1 none / 2 horizontal / 3 vertical.  is_mask = 0: src uint8 RGB [H,W,3], pad 127, dst uint8
+ * [size,size,3]; is_mask = 1: src uint8 0/1 [H,W] resized as float32, pad 0, np.around, dst uint8 0/1. */
+int disyolo_aug_place(const uint8_t* src, int is_mask, int image_h, int image_w, uint8_t* dst, int size,
+                      int new_w, int new_h, int dx, int dy, int flip, void* stream);
+/* add_salt_pepper_noise (:511-525): pixels (rows[i], cols[i]) <- 1 for i < nsalt, then <- 0 for the next npepper */
+int disyolo_aug_salt_pepper(uint8_t* image, int size, const int32_t* rows, const int32_t* cols, int nsalt,
+                            int npepper, void* stream);
+/* change_light (:527-535): L of HLS scaled by coeff, clipped */
+int disyolo_aug_change_light(uint8_t* image, int size, double coeff, void* stream);
+/* linearmotion_blur3C (:466-494), line length 3: angle 0/45/90/135, line_type 0 full / 1 right / 2 left */
+int disyolo_aug_motion_blur3(const uint8_t* src, uint8_t* dst, int size, int angle, int line_type, void* stream);
+/* image.astype(float32) / 255.0 (:411-413) */
+int disyolo_aug_to_float(const uint8_t* image, float* out, int64_t n, void* stream);
+
 /* ---- host helper of the checkpoint reader / writer (dis-yolo_amd/checkpoint.py; train_yolo3_mask.py:58,
  * 221-226 Saver.save / calculate_test_map.py:184-185 Saver.restore): CRC-32C (Castagnoli) of n bytes,
  * continuing from `crc` (0 to start) -- TensorFlow tensor bundles store it masked per tensor and per

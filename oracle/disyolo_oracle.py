@@ -934,3 +934,184 @@ def segmentation_miou(true_maps, pred_maps):
                 conf[a, b] += int(np.sum((t == a) * (p == b)))
     ious = [conf[c, c] / (conf[c, :].sum() + conf[:, c].sum() - conf[c, c]) for c in range(4)]
     return ious + [float(np.mean(ious))]
+
+
+# ---------------------------------------------------------------------------------------------
+# training-data pipeline (utils/train_data.py:44-276, 321-531) -- SURVEY.md 8(f2)
+# ---------------------------------------------------------------------------------------------
+def _point_in_polygon(xp, yp, x, y) -> int:
+    """scikit-image's point_in_polygon (measure/_pnpoly.pyx; the third-party routine behind
+    skimage.draw.polygon, which the reference calls at utils/train_data.py:331): 0 outside, 1 inside,
+    2 on a vertex, 3 on an edge.  Pinned by tests/golden/polygon.json (skimage 0.18.3 run in the build
+    container by tools/make_golden_polygon.py)."""
+    n, eps = len(xp), 1e-12
+    x0, y0 = xp[n - 1] - x, yp[n - 1] - y
+    l = r = 0
+    for i in range(n):
+        x1, y1 = xp[i] - x, yp[i] - y
+        if -eps < x1 < eps and -eps < y1 < eps:
+            return 2
+        if ((y0 > 0) != (y1 > 0)) and ((x0 * y1 - x1 * y0) / (y1 - y0) > 0):
+            r += 1
+        if ((y0 < 0) != (y1 < 0)) and ((x0 * y1 - x1 * y0) / (y1 - y0) < 0):
+            l += 1
+        x0, y0 = x1, y1
+    if (r & 1) != (l & 1):
+        return 3
+    return 1 if (r & 1) else 0
+
+
+def draw_polygon(ys, xs):
+    """skimage.draw.polygon(ys, xs) without a shape: (rr, cc) of every pixel of the bounding box
+    [max(0, min), ceil(max)] that is inside, on an edge or on a vertex"""
+    ys, xs = np.asarray(ys, np.float64), np.asarray(xs, np.float64)
+    rr, cc = [], []
+    for r in range(int(max(0, ys.min())), int(np.ceil(ys.max())) + 1):
+        for c in range(int(max(0, xs.min())), int(np.ceil(xs.max())) + 1):
+            if _point_in_polygon(xs, ys, float(c), float(r)):
+                rr.append(r)
+                cc.append(c)
+    return np.asarray(rr, np.int64), np.asarray(cc, np.int64)
+
+
+def instance_mask(polys, image_h: int, image_w: int) -> np.ndarray:
+    """load_mask for one instance (utils/train_data.py:325-336): polys = [{'type': 'out'|'in', 'all_points_x',
+    'all_points_y'}]; 'out' fills, 'in' clears (a hole), every polygon then sets its own vertex pixels"""
+    m = np.zeros((image_h, image_w), bool)
+    for poly in polys:
+        xs, ys = poly["all_points_x"], poly["all_points_y"]
+        rr, cc = draw_polygon(ys, xs)
+        m[rr, cc] = poly["type"] == "out"
+        m[np.array(ys), np.array(xs)] = True
+    return m
+
+
+def _taps(dn: int, sn: int):
+    scale = np.float64(sn) / dn
+    f = ((np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s0 = np.floor(f).astype(np.int64)
+    a = (f - s0.astype(np.float32)).astype(np.float32)
+    lo = s0 < 0
+    a[lo], s0[lo] = 0.0, 0
+    hi = s0 >= sn - 1
+    a[hi], s0[hi] = 0.0, sn - 1
+    return s0, np.minimum(s0 + 1, sn - 1), a
+
+
+def resize_linear_u8(src: np.ndarray, dst_w: int, dst_h: int) -> np.ndarray:
+    """cv2.resize(uint8 image, INTER_LINEAR), restated from OpenCV's 8-bit path (cv2 is not installed:
+    unpinned): coefficients rounded to 11 fractional bits, horizontal pass in integers, vertical pass
+    (b0*S0 + b1*S1 + 2^21) >> 22."""
+    src = np.asarray(src, np.uint8)
+    x0, x1, ax = _taps(dst_w, src.shape[1])
+    y0, y1, ay = _taps(dst_h, src.shape[0])
+    ax1 = np.rint(ax * np.float32(2048)).astype(np.int64)
+    ay1 = np.rint(ay * np.float32(2048)).astype(np.int64)
+    s = src.astype(np.int64)
+    rows = s[:, x0] * (2048 - ax1)[None, :, None] + s[:, x1] * ax1[None, :, None]
+    out = (rows[y0] * (2048 - ay1)[:, None, None] + rows[y1] * ay1[:, None, None] + (1 << 21)) >> 22
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def scale_and_crop(im_sized: np.ndarray, new_w: int, new_h: int, dx: int, dy: int, size: int, pad_value) -> np.ndarray:
+    """the placing half of apply_random_scale_and_crop (utils/train_data.py:452-464): [new_h,new_w,C] ->
+    [size,size,C] with its corner at (dx, dy), cropped where negative, padded elsewhere"""
+    if dx > 0:
+        im_sized = np.pad(im_sized, ((0, 0), (dx, 0), (0, 0)), mode="constant", constant_values=pad_value)
+    else:
+        im_sized = im_sized[:, -dx:, :]
+    if (new_w + dx) < size:
+        im_sized = np.pad(im_sized, ((0, 0), (0, size - (new_w + dx)), (0, 0)), mode="constant", constant_values=pad_value)
+    if dy > 0:
+        im_sized = np.pad(im_sized, ((dy, 0), (0, 0), (0, 0)), mode="constant", constant_values=pad_value)
+    else:
+        im_sized = im_sized[-dy:, :, :]
+    if (new_h + dy) < size:
+        im_sized = np.pad(im_sized, ((0, size - (new_h + dy)), (0, 0), (0, 0)), mode="constant", constant_values=pad_value)
+    return im_sized[:size, :size, :]
+
+
+def _flip(a: np.ndarray, flip: int) -> np.ndarray:
+    return a[:, ::-1] if flip == 2 else (a[::-1] if flip == 3 else a)
+
+
+def place_image(image_u8: np.ndarray, size: int, new_w: int, new_h: int, dx: int, dy: int, flip: int) -> np.ndarray:
+    """image_read up to the flip (utils/train_data.py:376-397): uint8 [size,size,3]"""
+    return np.ascontiguousarray(_flip(scale_and_crop(resize_linear_u8(image_u8, new_w, new_h), new_w, new_h, dx, dy, size, 127), flip))
+
+
+def place_mask(mask: np.ndarray, size: int, new_w: int, new_h: int, dx: int, dy: int, flip: int) -> np.ndarray:
+    """resize_mask for one instance (utils/train_data.py:418-436): float32 resize, pad 0, flip, np.around -> bool"""
+    m = resize_linear(np.asarray(mask, np.float32), new_w, new_h)[:, :, None]
+    m = _flip(scale_and_crop(m, new_w, new_h, dx, dy, size, 0.0), flip)
+    return np.around(np.squeeze(m, -1)).astype(bool)
+
+
+def salt_pepper(im: np.ndarray, rows, cols, nsalt: int) -> np.ndarray:
+    """add_salt_pepper_noise (utils/train_data.py:511-525) with the drawn coordinates passed in"""
+    im = im.copy()
+    im[rows[:nsalt], cols[:nsalt], :] = 1
+    im[rows[nsalt:], cols[nsalt:], :] = 0
+    return im
+
+
+def change_light(image: np.ndarray, coeff: float) -> np.ndarray:
+    """change_light (utils/train_data.py:527-535): cv2 RGB2HLS (8-bit: H/2, 255 L, 255 S), L scaled in float64,
+    clipped at 255, truncated, HLS2RGB.  OpenCV's documented formulas in float32 (cv2 not installed: unpinned)."""
+    f32 = np.float32
+    rgb = image.astype(f32) * f32(1.0 / 255.0)
+    r, g, b = rgb[..., 0], rgb[..., 1], rgb[..., 2]
+    vmax, vmin = np.maximum(r, np.maximum(g, b)), np.minimum(r, np.minimum(g, b))
+    diff, s_ = (vmax - vmin).astype(f32), (vmax + vmin).astype(f32)
+    l = (s_ * f32(0.5)).astype(f32)
+    grey = ~(diff > f32(1.1920929e-07))
+    safe = np.where(grey, f32(1), diff).astype(f32)
+    sat = np.where(l < f32(0.5), diff / np.where(grey, f32(1), s_), diff / np.where(grey, f32(1), (f32(2) - s_))).astype(f32)
+    d60 = (f32(60) / safe).astype(f32)
+    h = np.where(vmax == r, (g - b) * d60, np.where(vmax == g, (b - r) * d60 + f32(120), (r - g) * d60 + f32(240))).astype(f32)
+    h = np.where(h < 0, h + f32(360), h).astype(f32)
+    h, sat = np.where(grey, f32(0), h), np.where(grey, f32(0), sat)
+    sat8 = lambda v: np.clip(np.rint(v), 0, 255).astype(np.uint8)
+    H8, S8, L8 = sat8(h * f32(0.5)), sat8(sat * f32(255)), sat8(l * f32(255))
+    L = L8.astype(np.float64) * coeff
+    L[L > 255] = 255
+    L8 = L.astype(np.uint8)
+    hh, ll, ss = H8.astype(f32) * f32(2), L8.astype(f32) * f32(1.0 / 255.0), S8.astype(f32) * f32(1.0 / 255.0)
+    p2 = np.where(ll <= f32(0.5), ll * (f32(1) + ss), ll + ss - ll * ss).astype(f32)
+    p1 = (f32(2) * ll - p2).astype(f32)
+    hq = (hh * f32(1.0 / 60.0)).astype(f32)
+    hq = np.where(hq >= 6, hq - f32(6), hq).astype(f32)
+    sector = np.floor(hq).astype(np.int64)
+    f = (hq - sector.astype(f32)).astype(f32)
+    tab = np.stack([p2, p1, (p1 + (p2 - p1) * (f32(1) - f)).astype(f32), (p1 + (p2 - p1) * f).astype(f32)], axis=-1)
+    idx = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])       # (b, g, r) per sector
+    pick = idx[sector]
+    bo = np.take_along_axis(tab, pick[..., 0:1], -1)[..., 0]
+    go = np.take_along_axis(tab, pick[..., 1:2], -1)[..., 0]
+    ro = np.take_along_axis(tab, pick[..., 2:3], -1)[..., 0]
+    ro, go, bo = (np.where(ss == 0, ll, v).astype(f32) for v in (ro, go, bo))
+    return np.stack([sat8(ro * f32(255)), sat8(go * f32(255)), sat8(bo * f32(255))], axis=-1)
+
+
+def motion_blur3(img: np.ndarray, angle: int, line_type: int) -> np.ndarray:
+    """linearmotion_blur3C with lineLength 3 (utils/train_data.py:466-494; pyblur.LinearMotionBlur is not
+    installed: unpinned): 3x3 line kernel through the centre at 0/45/90/135 degrees, 'full' (0) three taps,
+    'right' (1) / 'left' (2) the centre and one neighbour, normalised; convolution with zero fill; uint8 truncation"""
+    dxa = {0: 1, 45: 1, 90: 0, 135: -1}[angle]
+    dya = 0 if angle == 0 else -1
+    k = np.zeros((3, 3), np.float32)
+    k[1, 1] = 1
+    if line_type != 2:
+        k[1 + dya, 1 + dxa] = 1
+    if line_type != 1:
+        k[1 - dya, 1 - dxa] = 1
+    w = np.float32(1.0) / np.float32(k.sum())
+    S = img.shape[0]
+    pad = np.zeros((S + 2, S + 2, 3), np.float32)
+    pad[1:-1, 1:-1] = img.astype(np.float32)
+    out = img.astype(np.float32) * w
+    # convolution: out[y,x] += k[1+dy,1+dx] * in[y-dy, x-dx], taps added in the kernel's order (a then b)
+    for use, (dy, dx) in ((line_type != 2, (dya, dxa)), (line_type != 1, (-dya, -dxa))):
+        if use:
+            out = out + pad[1 - dy:1 - dy + S, 1 - dx:1 - dx + S] * w
+    return np.clip(out.astype(np.int64), 0, 255).astype(np.uint8)

@@ -1,0 +1,52 @@
+"""CPU checks of the training-data pipeline's oracle: the polygon rasteriser against golden
+vectors produced by scikit-image itself (the reference's dependency, utils/train_data.py:331), and the
+placing / flipping helpers against hand-derived answers."""
+import json
+import os
+
+import numpy as np
+
+import disyolo_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "polygon.json")
+
+
+def test_polygon_rasteriser_matches_scikit_image_golden():
+    g = json.load(open(GOLD))
+    assert g["skimage"].startswith("0.") and len(g["cases"]) >= 20
+    for c in g["cases"]:
+        rr, cc = O.draw_polygon(c["y"], c["x"])
+        assert sorted(zip(rr.tolist(), cc.tolist())) == sorted(zip(c["rr"], c["cc"])), c["name"]
+
+
+def test_instance_mask_holes_and_vertex_pixels():
+    # a 10x10 square with a 4x4 hole: 'in' clears the interior AND the hole's own vertices are set again (:333-336)
+    polys = [{"type": "out", "all_points_x": [2, 12, 12, 2], "all_points_y": [2, 2, 12, 12]},
+             {"type": "in", "all_points_x": [5, 9, 9, 5], "all_points_y": [5, 5, 9, 9]}]
+    m = O.instance_mask(polys, 16, 16)
+    assert m[3, 3] and m[2, 2] and m[12, 12] and not m[13, 13]
+    assert not m[7, 7] and not m[6, 8]                      # inside the hole
+    assert m[5, 5] and m[9, 9] and m[5, 9] and m[9, 5]      # the hole's vertices stay set
+    assert not m[5, 7]                                      # the hole's edge between two vertices is cleared
+
+
+def test_scale_and_crop_places_pads_and_crops():
+    im = np.arange(4 * 6 * 1, dtype=np.float32).reshape(4, 6, 1) + 1
+    out = O.scale_and_crop(im, 6, 4, 2, 1, 8, 0.0)[..., 0]
+    assert out.shape == (8, 8) and out[1, 2] == 1 and out[4, 7] == 24 and out[0].sum() == 0 and out[:, :2].sum() == 0
+    out = O.scale_and_crop(im, 6, 4, -3, -2, 8, 127.0)[..., 0]       # negative offsets crop the image
+    assert out[0, 0] == im[2, 3, 0] and out[1, 2] == im[3, 5, 0] and out[2, 0] == 127 and out[0, 3] == 127
+    big = np.ones((20, 20, 1), np.float32)
+    assert O.scale_and_crop(big, 20, 20, -5, -5, 8, 0.0).shape == (8, 8, 1)
+
+
+def test_resize_u8_identity_and_place_mask_rounding():
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, (9, 7, 3)).astype(np.uint8)
+    assert np.array_equal(O.resize_linear_u8(img, 7, 9), img)         # same size: taps (s, s+1, 0) -> identity
+    m = np.zeros((4, 4), np.float32)
+    m[:, 2:] = 1
+    out = O.place_mask(m, 8, 8, 8, 0, 0, 1)
+    # 2x upscaling of a step edge: values 0, .25, .75, 1 across the edge -> np.around -> 0, 0, 1, 1
+    assert out[0].tolist() == [False, False, False, False, True, True, True, True]
+    assert np.array_equal(O.place_mask(m, 8, 8, 8, 0, 0, 2), out[:, ::-1])
