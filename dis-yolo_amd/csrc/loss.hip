@@ -197,36 +197,52 @@ __device__ __forceinline__ void bin_edges3(float lo, float hi, int e[4]) {
   e[2] = (int)rintf(lo + 2.f * sub);
   e[3] = (int)hi;
 }
-__global__ void mask_rois_kernel(const float* det, int max_det, const float* true_boxes, int G, const int* perm_det,
-                                 const int* perm_gt, int B, int Sm, int n_det, int n_gt, float iou_thr, int* rois,
-                                 int* roi_count) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// One 64-thread block per image: the image's detections, ground-truth boxes and permutations are staged in
+// LDS by all lanes, then lane 0 runs the (inherently sequential, order-defining) selection on them -- the
+// single-thread version spent 40 us in dependent global loads.
+__global__ __launch_bounds__(64) void mask_rois_kernel(const float* det_g, int max_det, const float* true_boxes_g, int G,
+                                                       const int* perm_det_g, const int* perm_gt_g, int B, int Sm, int n_det,
+                                                       int n_gt, float iou_thr, int* rois, int* roi_count) {
+  __shared__ float s_det[64 * 6];
+  __shared__ float s_tb[64 * 5];
+  __shared__ int s_pd[64], s_pg[64];
+  const int b = blockIdx.x;
   if (b >= B) return;
+  for (int i = threadIdx.x; i < max_det * 6 && i < 64 * 6; i += 64) s_det[i] = det_g[(size_t)b * max_det * 6 + i];
+  for (int i = threadIdx.x; i < G * 5 && i < 64 * 5; i += 64) s_tb[i] = true_boxes_g[(size_t)b * G * 5 + i];
+  for (int i = threadIdx.x; i < max_det && i < 64; i += 64) s_pd[i] = perm_det_g ? perm_det_g[b * max_det + i] : i;
+  for (int i = threadIdx.x; i < G && i < 64; i += 64) s_pg[i] = perm_gt_g ? perm_gt_g[b * G + i] : i;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const float* det = s_det;            // image b's rows, staged
+  const float* true_boxes = s_tb;
+  const int* perm_det = s_pd;
+  const int* perm_gt = s_pg;
   // trimmed lists (rows whose |coords| sum is non-zero), in row order
   int prow[64], grow[64];
   int np = 0, ng = 0;
   for (int r = 0; r < max_det && r < 64; ++r) {
-    const float* d = det + ((size_t)b * max_det + r) * 6;
+    const float* d = det + ((size_t)r) * 6;
     if (fabsf(d[0]) + fabsf(d[1]) + fabsf(d[2]) + fabsf(d[3]) != 0.f) prow[np++] = r;
   }
   for (int r = 0; r < G && r < 64; ++r) {
-    const float* t = true_boxes + ((size_t)b * G + r) * 5;
+    const float* t = true_boxes + ((size_t)r) * 5;
     if (fabsf(t[0]) + fabsf(t[1]) + fabsf(t[2]) + fabsf(t[3]) != 0.f) grow[ng++] = r;
   }
   // shuffled selection: first n_det proposals and first n_gt GT boxes in permuted order
   float rb[ROI_MAX][4];
   int nr = 0;
   for (int q = 0, taken = 0; q < max_det && taken < n_det; ++q) {
-    const int j = perm_det ? perm_det[b * max_det + q] : q;
+    const int j = perm_det[q];
     if (j < 0 || j >= np) continue;
-    const float* d = det + ((size_t)b * max_det + prow[j]) * 6;
+    const float* d = det + ((size_t)prow[j]) * 6;
     rb[nr][0] = d[0]; rb[nr][1] = d[1]; rb[nr][2] = d[2]; rb[nr][3] = d[3];
     ++nr; ++taken;
   }
   for (int q = 0, taken = 0; q < G && taken < n_gt; ++q) {
-    const int j = perm_gt ? perm_gt[b * G + q] : q;
+    const int j = perm_gt[q];
     if (j < 0 || j >= ng) continue;
-    const float* t = true_boxes + ((size_t)b * G + grow[j]) * 5;
+    const float* t = true_boxes + ((size_t)grow[j]) * 5;
     rb[nr][0] = t[1] - t[3] / 2.f; rb[nr][1] = t[0] - t[2] / 2.f;
     rb[nr][2] = t[1] + t[3] / 2.f; rb[nr][3] = t[0] + t[2] / 2.f;
     ++nr; ++taken;
@@ -237,7 +253,7 @@ __global__ void mask_rois_kernel(const float* det, int max_det, const float* tru
     float best = -INFINITY;
     int arg = 0;
     for (int j = 0; j < ng; ++j) {
-      const float* t = true_boxes + ((size_t)b * G + grow[j]) * 5;
+      const float* t = true_boxes + ((size_t)grow[j]) * 5;
       const float gy1 = t[1] - t[3] / 2.f, gx1 = t[0] - t[2] / 2.f, gy2 = t[1] + t[3] / 2.f, gx2 = t[0] + t[2] / 2.f;
       const float y1 = fmaxf(rb[r][0], gy1), x1 = fmaxf(rb[r][1], gx1);
       const float y2 = fminf(rb[r][2], gy2), x2 = fminf(rb[r][3], gx2);
@@ -462,7 +478,7 @@ extern "C" int disyolo_mask_rois(const float* detections, int max_det, const flo
     return disyolo_mask_rois(detections, max_det, true_boxes, G, perm_det, perm_gt, B, map_size, n_det, n_gt, iou_thresh,
                              rois, roi_count, s);
   });
-  hipLaunchKernelGGL(mask_rois_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, detections, max_det,
+  hipLaunchKernelGGL(mask_rois_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, detections, max_det,
                      true_boxes, G, perm_det, perm_gt, B, map_size, n_det, n_gt, iou_thresh, rois, roi_count);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;

@@ -1,5 +1,6 @@
 #include <stdlib.h>
 #include <string.h>
+#include <utility>
 #include <vector>
 #include "common.h"
 #include "runtime.h"
@@ -138,6 +139,29 @@ extern "C" int disyolo_cmdlist_sync(int from, int to) {
   g_rec->uses[from] = g_rec->uses[to] = true;
   return DISYOLO_OK;
 }
+// mark: remember this point of lane `lane`; wait: lane `lane` waits for a mark made EARLIER in the list -- unlike
+// cmdlist_sync the waiting lane does not wait for what the marked lane recorded after the mark.  Outside a
+// recording both are no-ops (mark returns -1).
+extern "C" int disyolo_cmdlist_mark(int lane) {
+  if (lane < 0 || lane >= NLANES) return DISYOLO_E_ARG;
+  if (!g_rec) return -1;
+  hipEvent_t ev;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+    disyolo_set_error("cmdlist_mark: hipEventCreate failed");
+    return DISYOLO_E_HIP;
+  }
+  g_rec->cmds.push_back(Cmd{nullptr, 2, 0, lane, 0, ev});
+  g_rec->uses[lane] = true;
+  return (int)g_rec->cmds.size() - 1;
+}
+extern "C" int disyolo_cmdlist_wait(int mark, int lane) {
+  if (!g_rec) return DISYOLO_OK;
+  DY_REQUIRE(lane >= 0 && lane < NLANES, "cmdlist_wait: bad lane");
+  DY_REQUIRE(mark >= 0 && mark < (int)g_rec->cmds.size() && g_rec->cmds[mark].kind == 2, "cmdlist_wait: %d is not a mark of this list", mark);
+  g_rec->cmds.push_back(Cmd{nullptr, 3, 0, mark, lane, nullptr});
+  g_rec->uses[lane] = true;
+  return DISYOLO_OK;
+}
 extern "C" int disyolo_cmdlist_end(void) {
   DY_REQUIRE(g_rec, "cmdlist_end: not recording");
   g_rec = nullptr;
@@ -178,17 +202,65 @@ extern "C" int disyolo_cmdlist_run_ex(void* l, int first, int last, void* stream
         }
     }
   }
+  // DISYOLO_LANE_TIMING=1 (diagnostic): time how long the caller's stream sits in each wait for a side lane --
+  // a timed event before and after the wait; reported (and the device synchronised) at the end of the range
+  static const bool lane_timing = getenv("DISYOLO_LANE_TIMING") && getenv("DISYOLO_LANE_TIMING")[0] == '1';
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> waits;
   for (int i = first; i < last; ++i) {
     Cmd& k = c->cmds[i];
     if (k.kind == 0) {
       const int rc = k.fn(lanes[k.lane]);
       if (rc) return rc;
+    } else if (k.kind == 2) {
+      if (hipEventRecord(k.ev, lanes[k.from]) != hipSuccess) {
+        disyolo_set_error("cmdlist_run: mark failed");
+        return DISYOLO_E_HIP;
+      }
+    } else if (k.kind == 3) {
+      // (a range that starts behind the mark waits on the event of the previous replay: replay whole steps)
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (lane_timing && k.to == 0) {
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, lanes[0]);
+      }
+      if (hipStreamWaitEvent(lanes[k.to], c->cmds[k.from].ev, 0) != hipSuccess) {
+        disyolo_set_error("cmdlist_run: wait failed");
+        return DISYOLO_E_HIP;
+      }
+      if (e0) {
+        (void)hipEventRecord(e1, lanes[0]);
+        waits.push_back({i, {e0, e1}});
+      }
     } else {
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (lane_timing && k.to == 0) {
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, lanes[0]);
+      }
       if (hipEventRecord(k.ev, lanes[k.from]) != hipSuccess || hipStreamWaitEvent(lanes[k.to], k.ev, 0) != hipSuccess) {
         disyolo_set_error("cmdlist_run: lane sync failed");
         return DISYOLO_E_HIP;
       }
+      if (e0) {
+        (void)hipEventRecord(e1, lanes[0]);
+        waits.push_back({i, {e0, e1}});
+      }
     }
+  }
+  if (!waits.empty()) {
+    (void)hipDeviceSynchronize();
+    float tot = 0.f;
+    for (auto& w : waits) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, w.second.first, w.second.second);
+      tot += ms;
+      if (ms > 0.02f) fprintf(stderr, "[lane timing] main lane waited %.1f us at command %d\n", ms * 1e3f, w.first);
+      (void)hipEventDestroy(w.second.first);
+      (void)hipEventDestroy(w.second.second);
+    }
+    fprintf(stderr, "[lane timing] total main-lane wait in this range: %.1f us\n", tot * 1e3f);
   }
   if (flags & 2) {
     for (int i = 1; i < NLANES; ++i)

@@ -111,6 +111,8 @@ _SIGS = {
     "disyolo_cmdlist_size": (C.c_int, [C.c_void_p]),
     "disyolo_cmdlist_set_lane": (C.c_int, [C.c_int]),
     "disyolo_cmdlist_sync": (C.c_int, [C.c_int, C.c_int]),
+    "disyolo_cmdlist_mark": (C.c_int, [C.c_int]),
+    "disyolo_cmdlist_wait": (C.c_int, [C.c_int, C.c_int]),
     "disyolo_cmdlist_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "disyolo_cmdlist_run_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "disyolo_cmdlist_side_stream": (C.c_void_p, [C.c_void_p]),
@@ -687,6 +689,19 @@ def set_lane(lane: int) -> None:
 
 def lane_sync(src: int, dst: int) -> None:
     _check(load().disyolo_cmdlist_sync(src, dst), "cmdlist_sync")
+
+
+def lane_mark(lane: int) -> int:
+    """remember this point of `lane` in the recording (-1 when not recording)"""
+    r = load().disyolo_cmdlist_mark(lane)
+    if r < -1:
+        _check(r, "cmdlist_mark")
+    return r
+
+
+def lane_wait(mark: int, lane: int) -> None:
+    if mark >= 0:
+        _check(load().disyolo_cmdlist_wait(mark, lane), "cmdlist_wait")
 
 
 def adam_step_dev(w, grad, m, v, n, n_decay, lr, b1, b2, eps, l2, step_counter, grad_scale=1.0) -> None:

@@ -744,6 +744,9 @@ class YOLONet(object):
         m = self.by_idx[82]
         L.psroi_loss(m.act, self.true_masks, cfg.MAX_BOX_PER_IMAGE, self.rois, self.roi_count, self.B, Sm, self.k,
                      self.mask_scale, m.dx, self.mask_loss, self.ws_aux if side else self.ws)
+        # the mask subnet's backward waits for THIS point of the side lane (not for the weight gradients
+        # that lane picks up afterwards: a whole-lane sync there kept the main lane idle for 250-500 us)
+        self._mask_mark = L.lane_mark(1) if side else -1
         if side:
             L.set_lane(0)
         L.yolo_loss([h.act for h in heads], self.labels, self.true_boxes, cfg.MAX_BOX_PER_IMAGE, self.B, self.S,
@@ -782,7 +785,7 @@ class YOLONet(object):
         for l in visit:
             pos = order.index(l) if not l.lock else -1
             if l.idx == 82 and getattr(self, "_mask_loss_pending", False):
-                L.lane_sync(1, 0)          # dscore comes from the side lane
+                L.lane_wait(self._mask_mark, 0)          # dscore comes from the side lane
                 self._mask_loss_pending = False
             if l.lock:
                 # locked layers still pass gradients through their residual add only in
@@ -822,7 +825,7 @@ class YOLONet(object):
                 L.image_pad8(self.images, self._img8)
                 L.conv2d_wgrad(self._wgrad1_desc, l.dx, l.cout, self._dw8, self.ws_aux)
                 L.copy2d_f32(self._dw8, l.dw, 9, 3 * l.cout, 8 * l.cout, 3 * l.cout)
-            else:
+            elif os.environ.get("DISYOLO_EXP_SKIP_WGRAD") != "1":     # (experiment: the step without its weight gradients)
                 L.conv2d_wgrad(l.wgrad_desc, dx, ld, l.dw, self.ws_aux)
             if side:
                 L.set_lane(0)

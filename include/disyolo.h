@@ -346,6 +346,10 @@ int disyolo_cmdlist_size(void* list);
  * cmdlist_run range forks the side lane after the caller's stream and joins it at the end. */
 int disyolo_cmdlist_set_lane(int lane);
 int disyolo_cmdlist_sync(int from_lane, int to_lane);
+/* finer edge: mark(lane) remembers this point of `lane` (returns the mark's id, -1 outside a recording);
+ * wait(mark, lane) makes `lane` wait for that point only -- not for what the marked lane recorded later */
+int disyolo_cmdlist_mark(int lane);
+int disyolo_cmdlist_wait(int mark, int lane);
 int disyolo_cmdlist_run(void* list, int first, int last, void* stream);
 /* same with explicit fork/join control (flags bit 0 = fork at the start, bit 1 = join at the
  * end) for a step replayed in several ranges, and the side lane's hipStream_t so a caller can
