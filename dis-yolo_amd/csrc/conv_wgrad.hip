@@ -378,22 +378,29 @@ __device__ __forceinline__ void dma16_imm(unsigned voff, i32x4 srd, unsigned lds
                : "memory");
 }
 
-template <int CO_T, int R, int ST>
-__global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3Params p) {
+// NW = 4: one wave per SIMD, every wave all nine taps.  NW = 8: two waves per SIMD -- waves 0-3 take taps 0-4,
+// waves 4-7 taps 5-8 of the same (input fragment, channel half): half the accumulators per wave, no reduction
+// between the groups, and two instruction streams per SIMD to interleave (the one-wave loop is issue-bound).
+template <int CO_T, int R, int ST, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_wgrad3x3_kernel(Wg3Params p) {
   constexpr int NJ = CO_T / 32;      // 16-channel gradient fragments per wave (the wave owns CO_T/2 channels)
-  constexpr int YD = CO_T / 32;      // gradient DMAs per wave per chunk = 32-channel sub-tiles of a stage
+  constexpr int YD = CO_T / 32;      // 32-channel sub-tiles of a gradient stage
+  constexpr int YDW = YD * 4 / NW;   // gradient DMAs per wave per chunk
+  constexpr int TPW = NW == 8 ? 5 : 9;   // taps per wave (the second group of 8 waves uses 4 of its 5 slots)
   constexpr int YST = YD * 4096;     // bytes per gradient stage: YD sub-tiles of [64 pixels][32 channels]
   constexpr int XRING = R * 4096;
   constexpr int XALLOC = XRING + 1024;   // + a copy of the ring's first 16 rows behind its end (see below)
   constexpr int PRE = ST - 1;
-  constexpr int LPT = 1 + YD;        // DMAs per wave per chunk
+  constexpr int LPT0 = 1 + YDW, LPT1 = YDW;   // DMAs per chunk of the waves that stage the input / that do not
   static_assert((R & (R - 1)) == 0 && ST >= 2, "ring");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int u = wave & 1, ch = wave >> 1;   // input-channel fragment, output-channel half
+  const int wq = wave & 3, tg = wave >> 2;  // position in the 4-wave group, tap group
+  const int u = wq & 1, ch = wq >> 1;       // input-channel fragment, output-channel half
+  const int tap0 = tg * 5, ntaps = NW == 8 ? (tg ? 4 : 5) : 9;
   int lin;
   {
     const int nblk = gridDim.x, bid = blockIdx.x;
@@ -415,10 +422,10 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3Params p) {
   // YD such images (channels 32j..32j+31): the lane's pixel is the same in all of them, so ONE pixel
   // walk serves the YD gradient DMAs (the sub-tile is the instruction's immediate offset) and one more
   // the input DMA.
-  const int drow = wave * 16 + (lane >> 2), dpc = lane & 3;
+  const int drow = wq * 16 + (lane >> 2), dpc = lane & 3;
   const int dlu = (dpc >> 1) ^ ((drow >> 2) & 1);
   const unsigned x_const = (unsigned)(ci0 + dlu * 16 + (dpc & 1) * 8) * 2u;
-  const int y_n = co0 + dlu * 16 + (dpc & 1) * 8;
+  const int y_n = co0 + (NW == 8 ? tg * 32 : 0) + dlu * 16 + (dpc & 1) * 8;   // 8 waves: group tg stages sub-tiles tg and tg + 2
   const unsigned y_const = (unsigned)y_n * 2u;
   PixState xs, ys;
   pix_init(xs, (c0 - p.leadB) * 64 + drow, p);
@@ -430,30 +437,37 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3Params p) {
     const unsigned slot = (unsigned)(c & (R - 1));
     // rows 0..15 of the ring are also kept behind its end: a fragment's second transposed read is the
     // first + 16 rows, which then never needs the wrap-around mask
-    if (wave == 0 && slot == 0) dma16(voff, srdx, lds0 + XRING);
-    dma16(voff, srdx, lds0 + slot * 4096u + wave * 1024u);
+    if (tg == 0) {
+      if (wave == 0 && slot == 0) dma16(voff, srdx, lds0 + XRING);
+      dma16(voff, srdx, lds0 + slot * 4096u + wq * 1024u);
+    }
     pix_advance64(xs, p);
   };
   auto issue_y = [&](int stage) {
     const int pix = pix_index(ys, p);
     const unsigned voff = pix >= 0 ? (unsigned)pix * yrow_bytes + y_const : OOB;
-    const unsigned dst = lds0 + XALLOC + stage * YST + wave * 1024u;
+    const unsigned dst = lds0 + XALLOC + stage * YST + (NW == 8 ? tg * 4096u : 0u) + wq * 1024u;
     dma16_imm<0>((y_n < p.ldy) ? voff : OOB, srdy, dst);
-    dma16_imm<64>((y_n + 32 < p.ldy) ? voff : OOB, srdy, dst + 4096u);
-    if constexpr (YD == 4) {
+    if constexpr (NW == 4) {
+      dma16_imm<64>((y_n + 32 < p.ldy) ? voff : OOB, srdy, dst + 4096u);
+      if constexpr (YD == 4) {
+        dma16_imm<128>((y_n + 64 < p.ldy) ? voff : OOB, srdy, dst + 8192u);
+        dma16_imm<192>((y_n + 96 < p.ldy) ? voff : OOB, srdy, dst + 12288u);
+      }
+    } else if constexpr (YD == 4) {
       dma16_imm<128>((y_n + 64 < p.ldy) ? voff : OOB, srdy, dst + 8192u);
-      dma16_imm<192>((y_n + 96 < p.ldy) ? voff : OOB, srdy, dst + 12288u);
     }
     pix_advance64(ys, p);
   };
 
   // ---- fragment read addresses
   const int g = lane >> 4, li = lane & 15, q = li >> 2, pc = li & 3;
-  int E[9];
+  int E[TPW];
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
+  for (int i = 0; i < TPW; ++i) {
+    const int tap = tap0 + i;
     const int rowc = (tap / 3 - 1) * p.P + (tap % 3 - 1) + 4 * g + q;
-    E[tap] = rowc * 64 + ((u ^ ((rowc >> 2) & 1)) * 32) + pc * 8;
+    E[i] = rowc * 64 + ((u ^ ((rowc >> 2) & 1)) * 32) + pc * 8;
   }
   int Fy[NJ];
 #pragma unroll
@@ -462,9 +476,9 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3Params p) {
     Fy[j] = XALLOC + (f >> 1) * 4096 + row * 64 + (((f & 1) ^ ((row >> 2) & 1)) * 32) + pc * 8;
   }
 
-  f32x4 acc[9][NJ];
+  f32x4 acc[TPW][NJ];
 #pragma unroll
-  for (int i = 0; i < 9; ++i)
+  for (int i = 0; i < TPW; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -479,10 +493,12 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3Params p) {
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   for (int t = 0; t < ((p.debug & 2) ? 1 : nsteps); ++t) {
     // (wave 0's occasional extra DMA only makes this wait for more than it needs)
-    if (t + PRE - 1 < nsteps)
-      wait_vmcnt<LPT*(PRE - 1)>();
-    else
+    if (t + PRE - 1 >= nsteps)
       wait_vmcnt<0>();
+    else if (tg == 0)
+      wait_vmcnt<LPT0*(PRE - 1)>();
+    else
+      wait_vmcnt<LPT1*(PRE - 1)>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (t + PRE < nsteps && !(p.debug & 4)) {
@@ -503,15 +519,16 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3Params p) {
         bfr[j] = __builtin_bit_cast(bf16x8, v);
       }
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const char* a = smem + ((E[tap] + T + ks * 2048) & (XRING - 1));
+      for (int i = 0; i < TPW; ++i) {
+        if (NW == 8 && i >= ntaps) continue;       // (wave-uniform: the last slot of the second tap group is unused)
+        const char* a = smem + ((E[i] + T + ks * 2048) & (XRING - 1));
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 1024));
         const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         const bf16x8 af = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc[tap][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc[i][j], 0, 0, 0);
       }
     }
   }
@@ -525,11 +542,13 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3Params p) {
   constexpr int CPR4 = WTN / 4;
   char* sw = smem + wave * (16 * ROWP);
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
+  for (int i = 0; i < TPW; ++i) {
+    if (NW == 8 && i >= ntaps) continue;
+    const int tap = tap0 + i;
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(sw + (g * 4 + r) * ROWP + (j * 16 + li) * 4) = acc[tap][j][r];
+      for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(sw + (g * 4 + r) * ROWP + (j * 16 + li) * 4) = acc[i][j][r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -618,7 +637,7 @@ void plan(const disyolo_conv_desc* d, int* bn, int* splits, int* steps_per_split
 
 
 struct Plan3 {
-  int co_t, R, splits, cps, chunks, tilesCi, tilesCo, leadA, leadB;
+  int co_t, R, splits, cps, chunks, tilesCi, tilesCo, leadA, leadB, st;
   size_t lds;
 };
 // tap-fused kernel: 3x3, stride 1, SAME pads, no fused concat, 32 | Cin, 4 | Cout
@@ -629,17 +648,27 @@ bool plan3(const disyolo_conv_desc* d, Plan3* q) {
   if (d->ksize != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->C1 != 0 || d->in_div != 1) return false;
   if (d->C0 % 32 || d->Cout % 4 || d->Cout < 32 || d->Ho != d->H || d->Wo != d->W) return false;
   const int P = d->W + 1, Hp = d->H + 1;
+  static const int cot_env = env_int("DISYOLO_WG3_COT", 0);
   q->co_t = d->Cout > 64 ? 128 : 64;
+  if (cot_env == 64) q->co_t = 64;
+  // A layer whose 128-channel tiles would need exactly two pixel splits gets 64-channel tiles and no split
+  // instead: same block count, the gradient is stored once, no partial sums to write and re-read.
+  if (cot_env == 0 && q->co_t == 128) {
+    const int t128 = (d->C0 / 32) * ceil_div(d->Cout, 128);
+    if ((target + t128 / 2) / t128 == 2) q->co_t = 64;
+  }
   q->leadB = ceil_div(P + 1, 64);
   q->leadA = 1 + P / 64;
-  const int need = 2 + q->leadA + q->leadB + 1;
-  q->R = need <= 8 ? 8 : (need <= 16 ? 16 : 32);
-  if (need > 32) return false;
-  q->lds = (size_t)q->R * 4096 + 1024 + 3 * 64 * (size_t)q->co_t * 2;
-  if (q->lds > 160 * 1024) {
-    q->co_t = 64;
-    q->lds = (size_t)q->R * 4096 + 1024 + 3 * 64 * 64 * 2;
-    if (q->lds > 160 * 1024) return false;
+  static const int st_env = env_int("DISYOLO_WG3_ST", 3);
+  q->st = st_env < 3 ? 3 : (st_env > 5 ? 5 : st_env);     // pipeline stages of the gradient image (prefetch depth st - 1)
+  for (;;) {
+    const int need = (q->st - 1) + q->leadA + q->leadB + 1;
+    q->R = need <= 8 ? 8 : (need <= 16 ? 16 : 32);
+    q->lds = (size_t)q->R * 4096 + 1024 + (size_t)q->st * 64 * (size_t)q->co_t * 2;
+    if (need <= 32 && q->lds <= 160 * 1024) break;
+    if (q->st > 3) { --q->st; continue; }
+    if (q->co_t == 128) { q->co_t = 64; continue; }
+    return false;
   }
   q->chunks = ceil_div((int64_t)d->B * Hp * P, 64);
   q->tilesCi = d->C0 / 32;
@@ -653,18 +682,29 @@ bool plan3(const disyolo_conv_desc* d, Plan3* q) {
   q->splits = ceil_div(q->chunks, q->cps);
   return true;
 }
-template <int CO_T, int R>
-int launch3(const Wg3Params& p, const Plan3& q, hipStream_t s) {
+template <int CO_T, int R, int NW, int ST>
+int launch3s(const Wg3Params& p, const Plan3& q, hipStream_t s) {
   static bool attr_done = false;
-  auto fn = conv_wgrad3x3_kernel<CO_T, R, 3>;
+  auto fn = conv_wgrad3x3_kernel<CO_T, R, ST, NW>;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       (void)hipGetLastError();
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL(fn, dim3(q.tilesCi * q.tilesCo * q.splits), dim3(256), q.lds, s, p);
+  hipLaunchKernelGGL(fn, dim3(q.tilesCi * q.tilesCo * q.splits), dim3(NW * 64), q.lds, s, p);
   return 0;
+}
+template <int CO_T, int R, int NW>
+int launch3w(const Wg3Params& p, const Plan3& q, hipStream_t s) {
+  if (q.st == 5) return launch3s<CO_T, R, NW, 5>(p, q, s);
+  if (q.st == 4) return launch3s<CO_T, R, NW, 4>(p, q, s);
+  return launch3s<CO_T, R, NW, 3>(p, q, s);
+}
+template <int CO_T, int R>
+int launch3(const Wg3Params& p, const Plan3& q, hipStream_t s) {
+  static const int waves = env_int("DISYOLO_WG3_WAVES", 4);
+  return waves == 4 ? launch3w<CO_T, R, 4>(p, q, s) : launch3w<CO_T, R, 8>(p, q, s);
 }
 
 }  // namespace

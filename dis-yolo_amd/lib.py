@@ -445,7 +445,8 @@ def conv2d_wgrad(d: ConvDesc, dy, dy_ld: int, dw, ws: Workspace) -> None:
     if TIMER is not None:
         # the partial-sum kernel and the slab reduction as two timed launches (same work, same order)
         kind, tn, ring, splits = conv2d_wgrad_plan(d)
-        name = ("conv_wgrad3x3_kernel<%d,%d,3>" % (tn, ring)) if kind == 1 else ("conv_wgrad_kernel<%d,3>" % tn)
+        waves = 8 if os.environ.get("DISYOLO_WG3_WAVES") == "8" else 4
+        name = ("conv_wgrad3x3_kernel<%d,%d,3,%d>" % (tn, ring, waves)) if kind == 1 else ("conv_wgrad_kernel<%d,3>" % tn)
         keep = d.tile
 
         def phase(bits):
