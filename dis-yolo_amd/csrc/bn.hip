@@ -4,6 +4,7 @@
 //
 // Replaces tf.nn.moments / tf.nn.batch_normalization / tf.assign(moving stats) /
 // tf.maximum(alpha*x, x) and their TF-autodiff gradients, yolo/yolo3_net_pos.py:68-107.
+#include <stdlib.h>
 #include "common.h"
 #include "runtime.h"
 
@@ -280,6 +281,12 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const bf16* src, bf
   }
 }
 
+// DISYOLO_EXP_BN (timing experiment, results are wrong): bit 0 skip the forward finalize, 1 the forward apply,
+// 2 the backward column reduction, 3 the backward finalize, 4 the backward apply
+int exp_bn() {
+  static const int v = getenv("DISYOLO_EXP_BN") ? atoi(getenv("DISYOLO_EXP_BN")) : 0;
+  return v;
+}
 int grid_for(int64_t n) {
   int64_t g = (n + 255) / 256;
   if (g > 256 * 8) g = 256 * 8;
@@ -312,6 +319,10 @@ extern "C" int disyolo_bn_finalize(const float* stats, int rows, int C, int64_t 
                                    float* scale, float* shift, float* mean, float* rstd, void* stream) {
   DY_REQUIRE(stats && gamma && beta && scale && shift && rows > 0 && C > 0 && count > 0, "bn_finalize: bad args");
   DY_RECORD_OR_RUN([=](void* s) { return disyolo_bn_finalize(stats, rows, C, count, gamma, beta, moving_mean, moving_var, decay, eps, scale, shift, mean, rstd, s); });
+  if (exp_bn() & 1) return DISYOLO_OK;
+  if (exp_bn() & 32)   // (twice: the second launch's cost is what one costs; decay applied twice -> results differ)
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, FIN_CPB)), dim3(256), 0, (hipStream_t)stream, stats, rows, C,
+                       1.0 / (double)count, gamma, beta, moving_mean, moving_var, decay, eps, scale, shift, mean, rstd);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, FIN_CPB)), dim3(256), 0, (hipStream_t)stream, stats, rows, C,
                      1.0 / (double)count, gamma, beta, moving_mean, moving_var, decay, eps, scale, shift, mean, rstd);
   DY_CHECK_LAUNCH();
@@ -333,6 +344,7 @@ extern "C" int disyolo_bn_act_fwd(const void* x, const float* scale, const float
   DY_REQUIRE(x && scale && shift && y && rows > 0 && C > 0 && C % 8 == 0, "bn_act_fwd: bad args (C %% 8 == 0)");
   DY_RECORD_OR_RUN([=](void* s) { return disyolo_bn_act_fwd(x, scale, shift, residual, y, rows, C, alpha, s); });
   const int64_t nvec = rows * C / 8;
+  if (exp_bn() & 2) return DISYOLO_OK;
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const uint4*)x,
                      scale, shift, (const uint4*)residual, (uint4*)y, nvec, C, alpha);
   DY_CHECK_LAUNCH();
@@ -361,13 +373,19 @@ extern "C" int disyolo_bn_act_bwd(const void* dy, const void* x, const float* sc
   float* part = (float*)workspace;
   float* c1 = part + (size_t)nb * C * 2;
   float* c2 = c1 + C;
+  if (!(exp_bn() & 4))
   hipLaunchKernelGGL(colreduce_kernel<1>, dim3(nb, ceil_div(chunks, cpb)), dim3(256), 0, s, (const uint4*)dy,
                      (const uint4*)x, scale, shift, mean, rstd, alpha, rows, C, rpb, part);
   DY_CHECK_LAUNCH();
+  if (exp_bn() & 64)
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_CPB)), dim3(256), 0, s, part, nb, C, 1.0 / (double)rows,
+                       scale, mean, rstd, dgamma, dbeta, c1, c2);
+  if (!(exp_bn() & 8))
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_CPB)), dim3(256), 0, s, part, nb, C, 1.0 / (double)rows,
                      scale, mean, rstd, dgamma, dbeta, c1, c2);
   DY_CHECK_LAUNCH();
   const int64_t nvec = rows * C / 8;
+  if (!(exp_bn() & 16))
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nvec)), dim3(256), 0, s, (const uint4*)dy, (const uint4*)x,
                      scale, shift, c1, c2, (uint4*)dx, nvec, C, alpha);
   DY_CHECK_LAUNCH();

@@ -256,18 +256,48 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* w, const float* 
   const float lr_t = (float)((double)*lr_dev * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   float ss = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float wi = w[i];
-    float gi = g[i] * gscale;
-    if (i < n_decay) {
+  auto one = [&](float wi, float gi, float& mi, float& vi, bool decay) {
+    gi *= gscale;
+    if (decay) {
       gi += l2 * wi;
       ss += wi * wi;
     }
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    w[i] = wi - lr_t * mi / (sqrtf(vi) + eps);
+    mi = b1 * mi + (1.f - b1) * gi;
+    vi = b2 * vi + (1.f - b2) * gi * gi;
+    return wi - lr_t * mi / (sqrtf(vi) + eps);
+  };
+  // 16-byte accesses over the aligned body (w, g, m, v are slices at the same offset of 16-byte aligned
+  // arenas: equally misaligned), scalars over the up to 3 leading and trailing elements
+  const int64_t head = (int64_t)(((16u - (unsigned)((size_t)w & 15u)) & 15u) >> 2) < n
+                           ? (int64_t)(((16u - (unsigned)((size_t)w & 15u)) & 15u) >> 2) : n;
+  const int64_t n4 = (n - head) >> 2;
+  float4* w4 = reinterpret_cast<float4*>(w + head);
+  const float4* g4 = reinterpret_cast<const float4*>(g + head);
+  float4* m4 = reinterpret_cast<float4*>(m + head);
+  float4* v4 = reinterpret_cast<float4*>(v + head);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 wi = w4[i], mi = m4[i], vi = v4[i];
+    const float4 gi = g4[i];
+    const int64_t e = head + (i << 2);
+    wi.x = one(wi.x, gi.x, mi.x, vi.x, e < n_decay);
+    wi.y = one(wi.y, gi.y, mi.y, vi.y, e + 1 < n_decay);
+    wi.z = one(wi.z, gi.z, mi.z, vi.z, e + 2 < n_decay);
+    wi.w = one(wi.w, gi.w, mi.w, vi.w, e + 3 < n_decay);
+    m4[i] = mi;
+    v4[i] = vi;
+    w4[i] = wi;
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x < 8) {
+    // thread t < 4: leading element t; 4 <= t < 8: trailing element t - 4
+    const int64_t tail0 = head + (n4 << 2);
+    const int64_t i = threadIdx.x < 4 ? (int64_t)threadIdx.x : tail0 + (threadIdx.x - 4);
+    const bool mine = threadIdx.x < 4 ? (int64_t)threadIdx.x < head : i < n;
+    if (mine) {
+      float mi = m[i], vi = v[i];
+      w[i] = one(w[i], g[i], mi, vi, i < n_decay);
+      m[i] = mi;
+      v[i] = vi;
+    }
   }
   if (part) {
     ss = wave_sum(ss);
@@ -276,14 +306,17 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* w, const float* 
     if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
   }
 }
-__global__ __launch_bounds__(64) void adam_fused_tail_kernel(int64_t* counter, const float* part, int nb, float coef,
-                                                             float* reg_out) {
+__global__ __launch_bounds__(256) void adam_fused_tail_kernel(int64_t* counter, const float* part, int nb, float coef,
+                                                              float* reg_out) {
+  __shared__ double sh[4];
   if (part && reg_out) {
     double s = 0.0;
-    for (int i = threadIdx.x; i < nb; i += 64) s += (double)part[i];
+    for (int i = threadIdx.x; i < nb; i += 256) s += (double)part[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (threadIdx.x == 0) reg_out[0] = (float)(s * coef);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) reg_out[0] = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) * coef);
   }
   if (threadIdx.x == 0) *counter += 1;
 }
@@ -446,6 +479,45 @@ extern "C" int disyolo_adam_step_dev(float* w, const float* grad, float* m, floa
   return DISYOLO_OK;
 }
 
+namespace {
+int adam_sweep_grid(int64_t n) {
+  int64_t g = (n + 1023) / 1024;
+  return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+}
+}  // namespace
+
+// One optimizer update as sweeps over slices of the arena + one finish: a recorded step runs the sweep of
+// a slice as soon as the slice's gradients are final (beside the rest of the backward pass) instead of
+// one sweep at the end of the critical chain.  Every sweep reads the same step counter; the finish
+// sums the l2 partials of all sweeps (fixed order: deterministic) and advances the counter.
+extern "C" int disyolo_adam_sweep_parts(int64_t n) { return n > 0 ? adam_sweep_grid(n) : 0; }
+
+extern "C" int disyolo_adam_sweep(float* w, const float* grad, float* m, float* v, int64_t n, int64_t n_decay,
+                                  const float* lr_dev, float beta1, float beta2, float eps, float l2,
+                                  const int64_t* step_counter, float grad_scale, float* parts, void* stream) {
+  DY_REQUIRE(w && grad && m && v && lr_dev && step_counter && n > 0 && n_decay >= 0 && n_decay <= n, "adam_sweep: bad args");
+  DY_REQUIRE(((size_t)w & 3) == 0 && ((size_t)w & 15) == ((size_t)grad & 15) && ((size_t)w & 15) == ((size_t)m & 15) &&
+                 ((size_t)w & 15) == ((size_t)v & 15),
+             "adam_sweep: w, grad, m, v must sit at the same offset modulo 16 bytes (slices of aligned arenas)");
+  DY_RECORD_OR_RUN([=](void* s) {
+    return disyolo_adam_sweep(w, grad, m, v, n, n_decay, lr_dev, beta1, beta2, eps, l2, step_counter, grad_scale, parts, s);
+  });
+  hipLaunchKernelGGL(adam_fused_kernel, dim3(adam_sweep_grid(n)), dim3(256), 0, (hipStream_t)stream, w, grad, m, v, n,
+                     n_decay, lr_dev, beta1, beta2, eps, l2, grad_scale, step_counter, parts);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+extern "C" int disyolo_adam_finish(int64_t* step_counter, const float* parts, int nparts, float l2, float* reg_loss_out,
+                                   void* stream) {
+  DY_REQUIRE(step_counter && nparts >= 0 && (!reg_loss_out || (parts && nparts > 0)), "adam_finish: bad args");
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_adam_finish(step_counter, parts, nparts, l2, reg_loss_out, s); });
+  hipLaunchKernelGGL(adam_fused_tail_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, step_counter, parts, nparts,
+                     0.5f * l2, reg_loss_out);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
 extern "C" size_t disyolo_adam_fused_workspace(int64_t n) { return n > 0 ? 4096 * sizeof(float) : 0; }
 
 extern "C" int disyolo_adam_step_fused(float* w, const float* grad, float* m, float* v, int64_t n, int64_t n_decay,
@@ -457,21 +529,10 @@ extern "C" int disyolo_adam_step_fused(float* w, const float* grad, float* m, fl
     disyolo_set_error("adam_fused: workspace too small");
     return DISYOLO_E_WORKSPACE;
   }
-  DY_RECORD_OR_RUN([=](void* s) {
-    return disyolo_adam_step_fused(w, grad, m, v, n, n_decay, lr_dev, beta1, beta2, eps, l2, step_counter, grad_scale,
-                                   reg_loss_out, workspace, workspace_bytes, s);
-  });
-  int grid = ceil_div(n, 256);
-  if (grid > 4096) grid = 4096;
-  hipStream_t s = (hipStream_t)stream;
   float* part = reg_loss_out ? (float*)workspace : nullptr;
-  hipLaunchKernelGGL(adam_fused_kernel, dim3(grid), dim3(256), 0, s, w, grad, m, v, n, n_decay, lr_dev, beta1, beta2, eps,
-                     l2, grad_scale, (const int64_t*)step_counter, part);
-  DY_CHECK_LAUNCH();
-  hipLaunchKernelGGL(adam_fused_tail_kernel, dim3(1), dim3(64), 0, s, step_counter, (const float*)part, grid, 0.5f * l2,
-                     reg_loss_out);
-  DY_CHECK_LAUNCH();
-  return DISYOLO_OK;
+  int rc = disyolo_adam_sweep(w, grad, m, v, n, n_decay, lr_dev, beta1, beta2, eps, l2, step_counter, grad_scale, part, stream);
+  if (rc) return rc;
+  return disyolo_adam_finish(step_counter, part, part ? adam_sweep_grid(n) : 0, l2, reg_loss_out, stream);
 }
 
 extern "C" size_t disyolo_l2_workspace(int64_t n) { return n > 0 ? 1024 * sizeof(float) : 0; }

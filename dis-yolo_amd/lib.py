@@ -101,6 +101,10 @@ _SIGS = {
     "disyolo_adam_step_dev": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int64] + [C.c_float] * 5 + [C.c_void_p, C.c_float,
                                                                                                  C.c_void_p]),
     "disyolo_adam_fused_workspace": (C.c_size_t, [C.c_int64]),
+    "disyolo_adam_sweep_parts": (C.c_int, [C.c_int64]),
+    "disyolo_adam_sweep": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int64, C.c_void_p] + [C.c_float] * 4 +
+                           [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "disyolo_adam_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "disyolo_adam_step_fused": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int64, C.c_void_p] + [C.c_float] * 4 +
                                 [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "disyolo_add_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
@@ -719,6 +723,21 @@ def adam_step_fused(w, grad, m, v, n, n_decay, lr_dev, b1, b2, eps, l2, step_cou
     _check(load().disyolo_adam_step_fused(_p(w), _p(grad), _p(m), _p(v), n, n_decay, _p(lr_dev), b1, b2, eps, l2,
                                           _p(step_counter), grad_scale, _p(reg_loss_out), _p(buf), buf.numel(),
                                           _stream()), "adam_step_fused")
+
+
+def adam_sweep_parts(n: int) -> int:
+    return load().disyolo_adam_sweep_parts(n)
+
+
+def adam_sweep(w, grad, m, v, n, n_decay, lr_dev, b1, b2, eps, l2, step_counter, grad_scale, parts) -> None:
+    """Adam over one slice of the variables (t = *step_counter + 1, counter untouched); l2 partials -> parts"""
+    _check(load().disyolo_adam_sweep(_p(w), _p(grad), _p(m), _p(v), n, n_decay, _p(lr_dev), b1, b2, eps, l2,
+                                     _p(step_counter), grad_scale, _p(parts), _stream()), "adam_sweep")
+
+
+def adam_finish(step_counter, parts, nparts, l2, reg_loss_out) -> None:
+    _check(load().disyolo_adam_finish(_p(step_counter), _p(parts), nparts, l2, _p(reg_loss_out), _stream()),
+           "adam_finish")
 
 
 def add_bf16(src, dst, accumulate: bool) -> None:

@@ -28,6 +28,7 @@ BF16 = torch.bfloat16
 F32 = torch.float32
 
 
+
 class Layer:
     __slots__ = ("idx", "cin", "cout", "k", "stride", "kind", "src", "src_up", "shortcut", "lock", "H", "W", "Ho",
                  "Wo", "w", "bias", "gamma", "beta", "mm", "mv", "scale", "shift", "mean", "rstd", "wp", "wdg", "raw",
@@ -160,7 +161,6 @@ class YOLONet(object):
             self.ws = L.Workspace(self.device)
             self.ws_aux = L.Workspace(self.device)      # scratch of the side lane (weight gradients)
             self.ws_det = L.Workspace(self.device)      # scratch of the detection filter (either lane)
-            self.ws_opt = L.Workspace(self.device)      # partial sums of the optimizer sweep
         self._reg_fresh = False
         # lock map: stage 1 = conv1-52 locked (shipped source), stage 2 = all trainable
         self.lock = dict(lock) if lock is not None else {i: (stage == 1 and i <= 52) for i in range(1, 83)}
@@ -172,7 +172,7 @@ class YOLONet(object):
         self._prog = None       # recorded command list of one training step
         self._prog_marks = []   # [(command index, layer)] all-reduce trigger points
         self._graph = None      # hipGraph of the recorded step (single GPU)
-        self._pack_table = None
+        self.opt_chunks = None      # slices of the arena the optimizer sweeps one by one (_plan_opt_chunks)
         self._side_streams = {}  # id(recorded list) -> its side lane as a torch stream
         self._progs = None      # [parity] -> (list, marks, bwd_end) of the pipelined step
         self.use_side_lane = os.environ.get("DISYOLO_SIDE_LANE", "1") != "0"
@@ -769,11 +769,13 @@ class YOLONet(object):
         heads = [self.by_idx[i] for i in (75, 74, 67, 66, 59, 58)]
         return heads + [l for l in reversed(self.layers) if l.idx not in self.HEAD_LAYERS]
 
-    def backward(self, on_layer_done=None) -> None:
+    def backward(self, on_layer_done=None, sweep: bool = False) -> None:
         """TF autodiff of total_loss restated layer by layer in reverse order.  Gradients of
         the trainable variables land in ``grad_arena``.  ``on_layer_done(layer)`` is called
         after a layer's parameter gradients are enqueued (used to overlap the RCCL
-        all-reduce with the rest of the backward pass)."""
+        all-reduce with the rest of the backward pass).  ``sweep`` (train_step, recorded steps): the
+        optimizer update of an arena slice is issued as soon as the slice's gradients are final
+        (optimizer_step() then only sweeps what is left and finishes the step)."""
         B = self.B
         for l in self.layers:
             l.grad_set = False
@@ -782,6 +784,13 @@ class YOLONet(object):
         # lane still runs the detection filter and the mask loss; the mask subnet follows.
         visit = self.backward_order()
         order = [l for l in visit if not l.lock]
+        # (data parallelism: the sweep must follow the bucket's all-reduce -- it stays in optimizer_step)
+        overlap_opt = sweep and self.dp is None and self.n_params > 0 and os.environ.get("DISYOLO_OPT_OVERLAP", "1") != "0"
+        if overlap_opt:
+            if self.opt_chunks is None:
+                self._plan_opt_chunks()
+            self._opt_swept = set()
+            self._opt_done = [set() for _ in self.opt_chunks]
         for l in visit:
             pos = order.index(l) if not l.lock else -1
             if l.idx == 82 and getattr(self, "_mask_loss_pending", False):
@@ -813,22 +822,29 @@ class YOLONet(object):
             # (with data parallelism every weight gradient stays on the side lane: the bucket all-reduce is
             # ordered after that lane only, and both lanes would share ws_aux otherwise)
             tail = 0 if self.dp is not None else self.tail_on_main
-            side = self.use_side_lane and (pos < len(order) - tail)
-            if side:
-                L.lane_sync(0, 1)
-                L.set_lane(1)
-            if l.kind == "lin":
-                L.colsum(l.dx, l.dbias, M, L.GRAD_LD, l.cout, self.ws_aux)   # bias gradient
-            if l.idx == 1:
-                # first layer through the same MFMA kernel: bf16 image padded to 8 channels,
-                # K = 9*8 rows of which 27 are real
-                L.image_pad8(self.images, self._img8)
-                L.conv2d_wgrad(self._wgrad1_desc, l.dx, l.cout, self._dw8, self.ws_aux)
-                L.copy2d_f32(self._dw8, l.dw, 9, 3 * l.cout, 8 * l.cout, 3 * l.cout)
-            elif os.environ.get("DISYOLO_EXP_SKIP_WGRAD") != "1":     # (experiment: the step without its weight gradients)
-                L.conv2d_wgrad(l.wgrad_desc, dx, ld, l.dw, self.ws_aux)
-            if side:
-                L.set_lane(0)
+            side = self.use_side_lane and (pos < len(order) - tail) and os.environ.get("DISYOLO_EXP_SKIP_WGRAD") != "2"
+            # enqueue order = host order: the data-gradient convs (critical chain, main lane) are issued
+            # before the weight gradient, which only needs dx -- the edge to the side lane is marked here,
+            # before those convs, so the side lane does not wait for them
+            mark = L.lane_mark(0) if side else None
+
+            def weight_gradient():
+                if side:
+                    L.lane_wait(mark, 1)
+                    L.set_lane(1)
+                if l.kind == "lin":
+                    L.colsum(l.dx, l.dbias, M, L.GRAD_LD, l.cout, self.ws_aux)   # bias gradient
+                if l.idx == 1:
+                    # first layer through the same MFMA kernel: bf16 image padded to 8 channels,
+                    # K = 9*8 rows of which 27 are real
+                    L.image_pad8(self.images, self._img8)
+                    L.conv2d_wgrad(self._wgrad1_desc, l.dx, l.cout, self._dw8, self.ws_aux)
+                    L.copy2d_f32(self._dw8, l.dw, 9, 3 * l.cout, 8 * l.cout, 3 * l.cout)
+                elif os.environ.get("DISYOLO_EXP_SKIP_WGRAD") not in ("1", "2"):     # (experiment: the step without its weight gradients)
+                    L.conv2d_wgrad(l.wgrad_desc, dx, ld, l.dw, self.ws_aux)
+                if side:
+                    L.set_lane(0)
+
             for mode, tgt, kw in l.dgrad_descs:
                 if mode == "direct":
                     self._accumulate_into(tgt, kw, dx, l.cin, l.k, l.stride)
@@ -838,6 +854,19 @@ class YOLONet(object):
                     up = tgt
                     L.upsample2x_bwd(kw["tmp"], up.grad, B, l.H, l.W, up.cout, 0, up.cout, accumulate=up.grad_set)
                     up.grad_set = True
+            weight_gradient()
+            if overlap_opt and side:
+                # the optimizer sweep of an arena slice (+ the re-pack of its layers) as soon as the slice's
+                # weight gradients are final, on the side lane behind them -- not at the end of the critical
+                # chain.  It rewrites the bf16 operands the data-gradient convs of these layers read: it
+                # waits for the main lane up to this point (all of them are enqueued by now)
+                ci = self._opt_chunk_of[l.idx]
+                self._opt_done[ci].add(l.idx)
+                if self._opt_done[ci] == self.opt_chunks[ci]["members"]:
+                    L.lane_wait(L.lane_mark(0), 1)
+                    L.set_lane(1)
+                    self._sweep_chunk(ci, 1.0)
+                    L.set_lane(0)
             if on_layer_done is not None:
                 on_layer_done(l)
         L.lane_sync(1, 0)
@@ -907,22 +936,87 @@ class YOLONet(object):
     def step_count(self) -> int:
         return int(self.step_dev.item())
 
+    # ---- optimizer: Adam as sweeps over slices of the arena ------------------------------
+    def _plan_opt_chunks(self) -> None:
+        """Slices of the regularised region [0, n_decay) in layer order, a few million variables each
+        (DISYOLO_OPT_CHUNK_M, default 8).  A slice can be swept as soon as the weight gradients of its
+        layers are final; each slice also owns the re-pack of its layers' bf16 operands and a fixed
+        range of the l2 partial sums (so the value of the l2 term does not depend on when it ran)."""
+        from .dp import plan_buckets
+        spans = []
+        for l in self.layers:
+            if l.lock:
+                continue
+            o, c = self.arena_slices[var_name(l.idx, "weights")]
+            if l.kind == "lin":
+                ob, cb = self.arena_slices[var_name(l.idx, "biases")]
+                assert ob == o + c
+                c += cb
+            spans.append((l.idx, o, c))
+        for (_, o, c), (_, o2, _) in zip(spans, spans[1:]):
+            assert o + c == o2, "arena must be contiguous in layer order"
+        assert not spans or (spans[0][1] == 0 and spans[-1][1] + spans[-1][2] == self.n_decay)
+        elems = int(float(os.environ.get("DISYOLO_OPT_CHUNK_M", "8")) * 1e6)
+        self.opt_chunks = []
+        self._opt_chunk_of = {}
+        parts = 0
+        by = {l.idx: l for l in self.layers}
+        for _, off, cnt in plan_buckets(spans, elems):
+            members = {idx for idx, o, c in spans if off <= o and o + c <= off + cnt}
+            jobs = [(by[i].w, by[i].wp, by[i].wdg, by[i].k, by[i].cin, by[i].cout, by[i].cout_pad)
+                    for i in sorted(members) if i > 1]
+            ch = {"off": off, "cnt": cnt, "members": members, "parts_off": parts,
+                  "nparts": L.adam_sweep_parts(cnt), "pack": L.PackTable(jobs, self.device) if jobs and not self.plan_only else None}
+            parts += ch["nparts"]
+            for i in members:
+                self._opt_chunk_of[i] = len(self.opt_chunks)
+            self.opt_chunks.append(ch)
+        self._opt_nparts = parts
+        self._opt_parts = None if self.plan_only else torch.zeros(max(parts, 1), dtype=torch.float32, device=self.device)
+        self._opt_swept = set()
+        self._opt_done = [set() for _ in self.opt_chunks]
+
+    def _sweep_chunk(self, ci: int, grad_scale: float) -> None:
+        """Adam over slice ci + the re-pack of its layers"""
+        ch = self.opt_chunks[ci]
+        o, c = ch["off"], ch["cnt"]
+        L.adam_sweep(self.arena[o:o + c], self.grad_arena[o:o + c], self.adam_m[o:o + c], self.adam_v[o:o + c], c, c,
+                     self.lr_dev, cfg.ADAM_BETA1, cfg.ADAM_BETA2, cfg.ADAM_EPSILON, self.l2, self.step_dev, grad_scale,
+                     self._opt_parts[ch["parts_off"]:ch["parts_off"] + ch["nparts"]])
+        if ch["pack"] is not None:
+            ch["pack"].run()
+        self._opt_swept.add(ci)
+
     def optimizer_step(self, grad_scale: float = 1.0) -> None:
         """tf.train.AdamOptimizer(1e-4).minimize (train_yolo3_mask.py:55) over the arena; the
         l2 regulariser's gradient (l2*w) is folded in for weights and biases.  The step count
-        lives on the device so the whole step can be replayed without host state."""
+        lives on the device so the whole step can be replayed without host state.  Slices that
+        backward() already swept (their gradients were final early) are skipped here; the finish
+        produces the l2 term of total_loss and advances the step count."""
         if self.n_params:
-            # one sweep: Adam (+ l2 gradient) and the value of the l2 term for the weights before the update
-            L.adam_step_fused(self.arena, self.grad_arena, self.adam_m, self.adam_v, self.n_params, self.n_decay,
-                              self.lr_dev, cfg.ADAM_BETA1, cfg.ADAM_BETA2, cfg.ADAM_EPSILON, self.l2,
-                              self.step_dev, grad_scale, self.reg_loss if self.n_decay else None, self.ws_opt)
+            if self.opt_chunks is None:
+                self._plan_opt_chunks()
+            for ci in range(len(self.opt_chunks)):
+                if ci not in self._opt_swept:
+                    self._sweep_chunk(ci, grad_scale)
+            nt = self.n_params - self.n_decay       # batch-norm gamma / beta: not regularised
+            if nt > 0:
+                o = self.n_decay
+                L.adam_sweep(self.arena[o:], self.grad_arena[o:], self.adam_m[o:], self.adam_v[o:], nt, 0, self.lr_dev,
+                             cfg.ADAM_BETA1, cfg.ADAM_BETA2, cfg.ADAM_EPSILON, self.l2, self.step_dev, grad_scale, None)
+            L.adam_finish(self.step_dev, self._opt_parts if self.n_decay else None, self._opt_nparts if self.n_decay else 0,
+                          self.l2, self.reg_loss if self.n_decay else None)
+            self._opt_swept = set()
+            self._opt_done = [set() for _ in self.opt_chunks]
             self._reg_fresh = True
-        if self._pack_table is None:
-            jobs = [(l.w, l.wp, l.wdg, l.k, l.cin, l.cout, l.cout_pad) for l in self.layers
-                    if not l.lock and l.idx > 1]
-            self._pack_table = L.PackTable(jobs, self.device) if jobs else False
-        if self._pack_table:
-            self._pack_table.run()
+
+    def repack(self) -> None:
+        """bf16 MFMA operands of every trainable layer from the f32 masters"""
+        if self.opt_chunks is None:
+            self._plan_opt_chunks()
+        for ch in self.opt_chunks:
+            if ch["pack"] is not None:
+                ch["pack"].run()
 
     def total_loss(self) -> torch.Tensor:
         """conf + class + coord + mask + l2 term as a device scalar (tf.losses.get_total_loss,
@@ -965,7 +1059,6 @@ class YOLONet(object):
         prog, marks, self._bwd_end = self._record_step(det_thresh, None)
         self.ws.frozen = True
         self.ws_aux.frozen = True
-        self.ws_opt.frozen = True
         self._prog, self._prog_marks = prog, marks
         if graph:
             if self.dp is not None:
@@ -1025,7 +1118,7 @@ class YOLONet(object):
                         marks.append((prog.size(), bi))
                 self.backward(mark)
             else:
-                self.backward()
+                self.backward(sweep=True)
             bwd_end = prog.size()
             self.optimizer_step(1.0 / self.dp.world_size if self.dp is not None else 1.0)
         return prog, marks, bwd_end
@@ -1074,7 +1167,7 @@ class YOLONet(object):
             self.dp.finish()
             self.optimizer_step(1.0 / self.dp.world_size)
         else:
-            self.backward()
+            self.backward(sweep=True)
             self.optimizer_step()
         # every term is the value for the weights BEFORE the update, like TF's fetch of total_loss
         # next to the train op (the l2 term comes out of the Adam sweep)

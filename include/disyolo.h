@@ -291,6 +291,18 @@ int disyolo_adam_step_fused(float* w, const float* grad, float* m, float* v, int
                             int64_t n_decay, const float* lr_dev, float beta1, float beta2, float eps,
                             float l2, int64_t* step_counter, float grad_scale, float* reg_loss_out,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* The same update as sweeps over slices of the variables + one finish (train_yolo3_mask.py:55 is one
+ * op over all variables; the slices only choose WHEN each part of it runs): a recorded step sweeps a
+ * slice as soon as its gradients are final, beside the rest of the backward pass.  Every sweep uses
+ * t = *step_counter + 1 and writes disyolo_adam_sweep_parts(n) l2 partial sums to `parts` (NULL: none;
+ * n_decay = how many leading elements of THIS slice are regularised); the finish sums the nparts
+ * partials of all sweeps in order into reg_loss_out (NULL: skip) and increments the counter. */
+int disyolo_adam_sweep_parts(int64_t n);
+int disyolo_adam_sweep(float* w, const float* grad, float* m, float* v, int64_t n, int64_t n_decay,
+                       const float* lr_dev, float beta1, float beta2, float eps, float l2,
+                       const int64_t* step_counter, float grad_scale, float* parts, void* stream);
+int disyolo_adam_finish(int64_t* step_counter, const float* parts, int nparts, float l2,
+                        float* reg_loss_out, void* stream);
 /* 0.5*l2*sum(w[0:n]^2) -> out f32[1] (only needed when the loss value is logged) */
 size_t disyolo_l2_workspace(int64_t n);
 int disyolo_l2_loss(const float* w, int64_t n, float l2, float* out, void* workspace,

@@ -7,6 +7,7 @@ Two oracle modes are used:
     bf16 rounding-boundary flips -> tolerances of a few bf16 ulps (2^-8 relative);
   * plain f32 (the reference's arithmetic): loose end-to-end tolerance, stated per test.
 """
+import math
 import numpy as np
 import pytest
 import torch
@@ -279,6 +280,45 @@ def test_adam_three_step_trace(dev):
         wr, mr, vr = O.adam_tf_step(wr, gr, mr, vr, t)
     torch.cuda.synchronize()
     np.testing.assert_allclose(w.cpu().double().numpy(), wr.numpy(), rtol=1.2e-7, atol=0)  # 1 f32 ulp
+
+
+@pytest.mark.parametrize("n,n_decay,off", [(4099, 1030, 0), (7, 3, 0), (64, 64, 0), (1025, 0, 0), (4099, 4099, 1), (2, 1, 3),
+                                          (1030, 517, 2)])
+def test_fused_adam_matches_the_plain_sweep(dev, n, n_decay, off):
+    """The one-sweep Adam (16-byte accesses, step count and learning rate on the device, l2 term out
+    of the same sweep) follows the f64 TF-form trace within 2 f32 ulp per step, for lengths that are not a
+    multiple of 4, slices that do not start on a 16-byte boundary and a decay boundary inside a vector; its l2 term is 0.5*l2*sum(w[:n_decay]^2)
+    of the weights BEFORE the update."""
+    g0 = torch.Generator().manual_seed(n)
+    w0 = torch.randn(n, generator=g0)
+    ws = L.Workspace(dev)
+    lr = torch.tensor([1e-4], device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    reg = torch.zeros(1, device=dev)
+    # slices of 16-byte aligned arenas, all at the same (possibly unaligned) offset
+    wa, ma, va, ga = (torch.zeros(n + 8, device=dev)[off:off + n] for _ in range(4))
+    wa.copy_(w0)
+    for t in (1, 2, 3):
+        g = torch.randn(n, generator=g0)
+        ga.copy_(g)
+        # one step of the TF-form update in f32 (TF's ApplyAdam forms 1-beta in f32 too) from the device's own
+        # state: per-step error (product rounding / contraction order), not its accumulation
+        f = np.float32
+        wr, mr, vr = wa.cpu().numpy(), ma.cpu().numpy(), va.cpu().numpy()
+        want_reg = 0.5 * 5e-4 * float((wr[:n_decay].astype(np.float64) ** 2).sum())
+        gr = g.numpy() * f(0.5)
+        gr[:n_decay] += f(5e-4) * wr[:n_decay]
+        mr = f(0.9) * mr + (f(1) - f(0.9)) * gr
+        vr = f(0.999) * vr + (f(1) - f(0.999)) * gr * gr
+        lr_t = f(1e-4 * math.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t))
+        wr = wr - lr_t * mr / (np.sqrt(vr) + f(1e-8))
+        L.adam_step_fused(wa, ga, ma, va, n, n_decay, lr, 0.9, 0.999, 1e-8, 5e-4, cnt, 0.5, reg, ws)
+        torch.cuda.synchronize()
+        assert int(cnt.cpu()) == t
+        np.testing.assert_allclose(ma.cpu().numpy(), mr, rtol=3e-7, atol=3e-8)
+        np.testing.assert_allclose(va.cpu().numpy(), vr, rtol=3e-7, atol=3e-8)
+        np.testing.assert_allclose(wa.cpu().numpy(), wr, rtol=3e-7, atol=3e-8)
+        assert abs(float(reg.cpu()) - want_reg) <= 2e-6 * max(want_reg, 1e-30)
 
 
 @pytest.mark.parametrize("graph", [False, True])

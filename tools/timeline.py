@@ -5,7 +5,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     r["s"] = int(r["Start_Timestamp"]); r["e"] = int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
-adam = [i for i, r in enumerate(rows) if "adam_dev" in r["Kernel_Name"]]
+adam = [i for i, r in enumerate(rows) if "adam_fused_kernel" in r["Kernel_Name"]]
 i0, i1 = (adam[-3], adam[-2]) if len(adam) >= 3 else (adam[-2], adam[-1])
 # a step = kernels after adam(i0)'s pack kernel .. adam(i1) + pack
 step = rows[i0 + 1:i1 + 2]
@@ -29,7 +29,7 @@ def first(name):
     for r in step:
         if name in r["Kernel_Name"]: return (r["s"] - t0) / 1e3
     return None
-for name in ("conv_first", "yolo_loss_kernel", "bn_bwd_finalize", "adam_dev"):
+for name in ("conv_first", "yolo_loss_kernel", "bn_bwd_finalize", "adam_fused_kernel"):
     print("first %-20s at %8.1f us" % (name, first(name) or -1))
 # per-queue per-kernel-class totals
 for q, rs in byq.items():
@@ -48,7 +48,7 @@ for g in sorted(gaps, reverse=True)[:12]:
     print("  %.1f us after %s -> %s" % (g[0] / 1e3, g[1], g[2]))
 # backward window: per-queue busy
 tb = [r for r in step if "bn_bwd_finalize" in r["Kernel_Name"]][0]["s"]
-ta = [r for r in step if "adam_dev" in r["Kernel_Name"]][0]["s"]
+ta = [r for r in step if "adam_fused_kernel" in r["Kernel_Name"]][0]["s"]
 for q, rs in byq.items():
     w = [r for r in rs if r["s"] >= tb and r["e"] <= ta]
     f = [r for r in rs if r["e"] <= tb]
