@@ -1120,6 +1120,8 @@ int validate(const disyolo_conv_desc* d) {
 
 }  // namespace
 
+extern "C" size_t disyolo_conv_desc_size(void) { return sizeof(disyolo_conv_desc); }
+
 extern "C" int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d) {
   if (!d) return DISYOLO_E_ARG;
   const int M = d->B * d->Ho * d->Wo;

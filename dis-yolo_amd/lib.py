@@ -44,6 +44,7 @@ class ConvDesc(C.Structure):
 _SIGS = {
     "disyolo_version": (C.c_int, []),
     "disyolo_last_error": (C.c_char_p, []),
+    "disyolo_conv_desc_size": (C.c_size_t, []),
     "disyolo_conv2d_stats_rows": (C.c_int, [C.POINTER(ConvDesc)]),
     "disyolo_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "disyolo_conv2d_tile": (C.c_int, [C.POINTER(ConvDesc)] + [C.POINTER(C.c_int)] * 4),
@@ -148,6 +149,9 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        if lib.disyolo_conv_desc_size() != C.sizeof(ConvDesc):
+            raise DisyoloError("%s was built from a different include/disyolo.h (conv descriptor %d bytes, this "
+                               "binding %d): rebuild it" % (LIB_PATH, lib.disyolo_conv_desc_size(), C.sizeof(ConvDesc)))
         _lib = lib
     return _lib
 

@@ -79,6 +79,8 @@ typedef struct disyolo_conv_desc {
   float* stats;           /* f32 [disyolo_conv2d_stats_rows][Cout][2] or NULL         */
 } disyolo_conv_desc;
 
+/* sizeof(disyolo_conv_desc) as this library was built: a binding checks its mirror against it */
+size_t disyolo_conv_desc_size(void);
 /* rows of the `stats` partial buffer a call with this descriptor writes */
 int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d);
 int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream);
