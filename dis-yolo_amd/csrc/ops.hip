@@ -1,5 +1,6 @@
 // First-layer convolution, weight packing, Adam and the l2 term.
 #include <stdarg.h>
+#include <stdlib.h>
 #include "common.h"
 #include "runtime.h"
 
@@ -98,6 +99,146 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- conv 1 on the f32 matrix cores ----------------------------------------------------------
+// The same layer as an exact-f32 GEMM: D[channel][pixel] = sum_k W[k][channel] * X[pixel][k], k = (kh,kw,ci)
+// = 27 padded to 28, on v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate, no reduced-precision step): 14 MFMAs
+// per 32 pixels x 32 channels.  The thread-per-pixel kernel above is bound by its wave-uniform scalar weight
+// loads (90-100 us at B = 8, 576^2; packing two channels per v_pk_fma_f32 changed nothing); here the weights
+// sit in 14 VGPRs per lane for the whole kernel (A operand: lane l holds W[k = 2j + (l>>5)][channel l&31])
+// and the image is the B operand (lane l: pixel l&31, k = 2j + (l>>5)).  A tile is 32 consecutive pixels of
+// one image row (W % 32 == 0): its 3 x 34 x 3 input floats are fetched as three contiguous 408-byte runs
+// (6 coalesced loads per wave instead of 14 scattered ones -- those cost 49 of 108 us), one tile ahead,
+// parked in LDS, and read back as operands with a 12-byte lane stride (3 is odd: conflict-free).
+// With channels as rows the accumulator layout gives every lane ITS pixel's channels 4 at a time (rows
+// (r&3) + 8(r>>2) + 4(l>>5)): scaled, activated, packed to 8-byte pieces, staged through LDS (16-byte chunk
+// index XOR pixel&3) and stored as whole 64-byte pixel rows, 1 KiB per instruction.
+// Measured at B = 8, 576^2: 75-82 us against 104-108 us for the VALU kernel on the same box.  The parts add
+// up instead of overlapping (14 MFMAs 42 us, epilogue math 9 us, stores 12-14 us, the rest 17 us): the f32 MFMA
+// runs at the vector-f32 rate and keeps the SIMD's VALU busy, so other waves' epilogues do not hide under it.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __restrict__ img, const float* __restrict__ sw,
+                                                              const float* __restrict__ ssc, const float* __restrict__ ssh,
+                                                              bf16* __restrict__ y, int B, int H, int W, float alpha) {
+  constexpr int ROW = 104;                 // 34 pixels x 3 channels = 102 floats, padded
+  __shared__ uint4 stage[4][32 * 4];       // per wave: 32 pixels x 64 bytes of output
+  __shared__ float xin[4][2][3 * ROW];     // per wave, double-buffered: the tile's 3 input rows
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  const int total = B * H * W;
+  const int tiles = total >> 5;            // W % 32 == 0
+  // a wave owns a contiguous range of tiles: the tile coordinates advance with scalar adds, no divisions
+  const int nwaves = gridDim.x * 4, wid = blockIdx.x * 4 + wave;
+  const int per = (tiles + nwaves - 1) / nwaves;
+  int tile = wid * per;
+  const int tend = min(tile + per, tiles);
+  if (tile >= tend) return;
+  float wreg[14];
+#pragma unroll
+  for (int j = 0; j < 14; ++j) {
+    const int k = 2 * j + half;
+    wreg[j] = k < 27 ? sw[k * 32 + col] : 0.f;
+  }
+  float sc[16], sh[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int ch = (r & 3) + 8 * (r >> 2) + 4 * half;
+    sc[r] = ssc[ch];
+    sh[r] = ssh[ch];
+  }
+  // byte offset in a tile's LDS image of this lane's operand of MFMA j (k = 2j + half -> tap (kh, kw), channel ci)
+  int xoff[14];
+#pragma unroll
+  for (int j = 0; j < 14; ++j) {
+    const int k0 = 2 * j, k1 = 2 * j + 1;
+    const int o0 = ((k0 / 3) / 3) * ROW + ((k0 / 3) % 3) * 3 + k0 % 3;
+    const int o1 = k1 < 27 ? ((k1 / 3) / 3) * ROW + ((k1 / 3) % 3) * 3 + k1 % 3 : 0;
+    xoff[j] = ((half ? o1 : o0) + col * 3) * 4;
+  }
+  const bool k27 = half != 0;              // MFMA 13, upper lane half: k = 27 does not exist (its weight is 0 too)
+  // fetch lanes: element e = lane + 64 t of a 102-float row run; the first pixel of the run is left of the
+  // image in the first tile of a row, the last one right of it in the last tile
+  const bool e1_in = lane + 64 < 102;
+  const bool left0 = lane < 3, right1 = (lane + 64) / 3 == 33;
+  int x0 = (tile << 5) % W, m2 = (tile << 5) / W;   // m2 = b*H + y (scalar)
+  int yy = m2 % H;
+  x0 = __builtin_amdgcn_readfirstlane(x0);
+  m2 = __builtin_amdgcn_readfirstlane(m2);
+  yy = __builtin_amdgcn_readfirstlane(yy);
+  auto fetch = [&](bool live, int fx0, int fm2, int fyy, float* r) {   // input rows, global -> registers
+    const bool lok = !(fx0 == 0 && left0), rok = !(fx0 + 32 == W && right1) && e1_in;
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+      const int iy = fyy + rr - 1;
+      const bool rowok = live && ((unsigned)iy < (unsigned)H);
+      const float* rowp = img + ((size_t)(fm2 + rr - 1) * W + fx0 - 1) * 3 + lane;
+      r[rr * 2 + 0] = (rowok && lok) ? rowp[0] : 0.f;
+      r[rr * 2 + 1] = (rowok && rok) ? rowp[64] : 0.f;
+    }
+  };
+  auto park = [&](int buf, const float* r) {
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+      xin[wave][buf][rr * ROW + lane] = r[rr * 2 + 0];
+      if (lane + 64 < ROW) xin[wave][buf][rr * ROW + lane + 64] = r[rr * 2 + 1];
+    }
+  };
+  auto advance = [&]() {
+    x0 += 32;
+    if (x0 == W) {
+      x0 = 0;
+      ++m2;
+      yy = yy + 1 == H ? 0 : yy + 1;
+    }
+  };
+  float r[6];
+  int buf = 0;
+  fetch(true, x0, m2, yy, r);
+  park(0, r);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (; tile < tend; ++tile) {
+    advance();
+    fetch(tile + 1 < tend, x0, m2, yy, r);   // the next tile, in flight under this tile's MFMAs
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    const char* xb = reinterpret_cast<const char*>(&xin[wave][buf][0]);
+    float xv[14];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) xv[j] = *reinterpret_cast<const float*>(xb + xoff[j]);
+    if (k27) xv[13] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[j], xv[j], acc, 0, 0, 0);
+    // this lane: pixel `col` of the tile, channels 8g + 4*half .. +3 for g = 0..3
+    uint2* st2 = reinterpret_cast<uint2*>(&stage[wave][0]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = leaky(acc[g * 4 + q] * sc[g * 4 + q] + sh[g * 4 + q], alpha);
+      uint2 o;
+      o.x = pack2(v[0], v[1]);
+      o.y = pack2(v[2], v[3]);
+      st2[(col * 4 + (g ^ (col & 3))) * 2 + half] = o;
+    }
+    park(buf ^ 1, r);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint4* dst = reinterpret_cast<uint4*>(y + ((size_t)tile << 5) * 32);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int c = it * 64 + lane;        // 16-byte chunk of the tile's contiguous 2 KiB of output
+      const int p = c >> 2, g = c & 3;
+      dst[c] = stage[wave][p * 4 + (g ^ (p & 3))];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    buf ^= 1;
   }
 }
 
@@ -350,6 +491,17 @@ extern "C" int disyolo_conv_first_fwd(const float* images, const float* w_hwio, 
   const int64_t total = (int64_t)B * H * W;
   int grid = ceil_div(total, 256);
   if (grid > 256 * 16) grid = 256 * 16;
+  // DISYOLO_FIRST_VALU=1: the thread-per-pixel VALU kernel (sequential 27-tap FMA chain per output)
+  static const bool valu = getenv("DISYOLO_FIRST_VALU") && getenv("DISYOLO_FIRST_VALU")[0] == '1';
+  if (!valu && W % 32 == 0 && total < (1LL << 31) / 3) {
+    const int64_t tiles = total / 32;
+    int g2 = (int)((tiles + 3) / 4);
+    if (g2 > 256 * 4) g2 = 256 * 4;
+    hipLaunchKernelGGL(conv_first_mfma_kernel, dim3(g2), dim3(256), 0, (hipStream_t)stream, images, w_hwio, scale, shift,
+                       (bf16*)y_bf16, B, H, W, alpha);
+    DY_CHECK_LAUNCH();
+    return DISYOLO_OK;
+  }
   hipLaunchKernelGGL(conv_first_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, images, w_hwio, scale,
                      shift, (bf16*)y_bf16, B, H, W, alpha, 0.f);
   DY_CHECK_LAUNCH();

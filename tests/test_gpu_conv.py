@@ -224,14 +224,17 @@ def test_conv_stats_and_bn_finalize(dev, tile):
     check(act, want, 2.0 ** -6, 2e-2)
 
 
-def test_conv_first_layer(dev):
-    g = torch.Generator().manual_seed(3)
-    x = torch.rand(2, 20, 24, 3, generator=g)
+@pytest.mark.parametrize("B,H,W", [(2, 20, 24), (2, 9, 64), (1, 5, 96), (3, 33, 32), (1, 1, 32)])
+def test_conv_first_layer(dev, B, H, W):
+    """W % 32 == 0 runs the f32-MFMA kernel (32-pixel row tiles), other widths the thread-per-pixel kernel;
+    both are exact-f32 products and sums, the output is rounded to bf16 once."""
+    g = torch.Generator().manual_seed(3 + W)
+    x = torch.rand(B, H, W, 3, generator=g)
     w = torch.randn(3, 3, 3, 32, generator=g) * 0.2
     scale = torch.rand(32, generator=g) + 0.5
     shift = torch.randn(32, generator=g) * 0.1
     want = O.leaky_relu(O.conv2d_same(x.double(), w.double(), 1) * scale.double() + shift.double(), 0.1)
-    y = torch.empty(2, 20, 24, 32, dtype=torch.bfloat16, device=dev)
+    y = torch.empty(B, H, W, 32, dtype=torch.bfloat16, device=dev)
     L.conv_first_fwd(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev), y)
     torch.cuda.synchronize()
     check(y, want, 2.0 ** -8, 1e-5)
