@@ -179,50 +179,41 @@ def repeated(step, steps: int, repeats: int, world: int, dev):
 
 
 def secondary_measurements(args, dev):
-    """same process, after the headline (single GPU): the stage-2 train step (all 82 layers trainable) and
-    the B=32 hipGraph-replayed inference of BASELINE.json configs[3]"""
+    """after the headline (single GPU): the stage-2 train step (all 82 layers trainable) and the B=32
+    hipGraph-replayed inference of BASELINE.json configs[3] -- each in a CHILD process running this file.
+    A process that has created and freed many GB of device tensors runs later workloads on worse-mapped
+    memory (the B=32 inference drops from 5.1 k to 3.9 k img/s after a training net lived in the same
+    process; tools/micro/infer_after_alloc.py shows it with allocations alone), so every line is measured
+    the way a user would run it: in a fresh process."""
+    import subprocess
     out = {}
     S = args.size
+    common = ["--size", str(S), "--steps", "10", "--warmup", "3", "--repeats", "5", "--autotune", args.autotune,
+              "--no-secondary", "--no-cpu-baseline", "--no-kernel-events"]
+
+    def child(extra):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra + common, stdout=subprocess.PIPE,
+                           stderr=subprocess.DEVNULL, timeout=600)
+        lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            raise RuntimeError("child bench exited with %d" % r.returncode)
+        return json.loads(lines[-1])
+
     try:
-        B = args.batch
-        net = YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=2, seed=0)
-        net.set_batch(synthetic_batch(B, S, seed=4321))
-        net.shuffle_seed = 99
-        if args.autotune == "on":
-            net.autotune()
-        net.build_program()
-        step = lambda: net.train_step(None, want_loss=False)
-        for _ in range(3):
-            step()
-        med, ts = repeated(step, 10, 5, 1, dev)
+        d = child(["--stage", "2", "--batch", str(args.batch)])
         gf = TRAIN_GFLOP_PER_IMG_576[2] * (S / 576.0) ** 2
-        out["train_stage2"] = {"workload": "train_step_B%d_%dx%d_3class_stage2" % (B, S, S), "value": round(B * 10 / med, 2),
-                               "unit": "images/sec", "ms_per_step": round(med / 10 * 1e3, 3), "steps": 10, "repeats": len(ts),
-                               "frac_of_mfma_peak": round(gf * B * 10 / med / 1e3 / MFMA_PEAK_TFLOPS, 4),
-                               "final_total_loss": round(float(net.total_loss().cpu()), 4)}
-        del net
-        torch.cuda.empty_cache()
+        out["train_stage2"] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
+                               "ms_per_step": d["ms_per_step"], "steps": d["steps"], "repeats": d.get("repeats"),
+                               "frac_of_mfma_peak": round(gf * d["value"] / 1e3 / MFMA_PEAK_TFLOPS, 4),
+                               "final_total_loss": d["config"].get("final_total_loss"), "process": "child"}
     except Exception as e:   # a secondary line must never cost the headline
         out["train_stage2"] = {"error": repr(e)[:200]}
     try:
-        B = 32
-        net = YOLONet(training=False, device=dev, image_size=S, batch_size=B, stage=1, seed=0)
-        batch = synthetic_batch(B, S, seed=1234)
-        net._set_inputs(batch["images"], batch["clip_window"])
-        if args.autotune == "on":
-            net.autotune()
-        net.build_infer_program(graph=True)
-        step = lambda: net.infer()
-        for _ in range(3):
-            step()
-        med, ts = repeated(step, 10, 5, 1, dev)
-        gf = FWD_GFLOP_PER_IMG_576 * (S / 576.0) ** 2
-        out["infer_b32_graph"] = {"workload": "infer_B32_%dx%d_3class_hipgraph (network + NMS + PS-RoI mask assembly)" % (S, S),
-                                  "value": round(B * 10 / med, 2), "unit": "images/sec", "ms_per_step": round(med / 10 * 1e3, 3),
-                                  "steps": 10, "repeats": len(ts),
-                                  "frac_of_mfma_peak": round(gf * B * 10 / med / 1e3 / MFMA_PEAK_TFLOPS, 4)}
-        del net
-        torch.cuda.empty_cache()
+        d = child(["--task", "infer", "--batch", "32"])
+        out["infer_b32_graph"] = {"workload": d["config"]["workload"] + "_hipgraph (network + NMS + PS-RoI mask assembly)",
+                                  "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                                  "steps": d["steps"], "repeats": 5,
+                                  "frac_of_mfma_peak": d["model_flops"]["frac_of_mfma_peak"], "process": "child"}
     except Exception as e:
         out["infer_b32_graph"] = {"error": repr(e)[:200]}
     return out

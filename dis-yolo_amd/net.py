@@ -328,14 +328,35 @@ class YOLONet(object):
                     raise NotImplementedError(
                         "layer %d is locked but has trainable layers upstream; only the reference's two stages "
                         "(conv1-52 locked, or nothing locked) are supported (yolo/yolo3_net_pos.py:155-156)" % l.idx)
+        # activation tensors are views into ONE allocation: a process that has allocated and freed a lot of
+        # device memory gets later allocations on worse-mapped memory (B = 32 inference 4.8 -> 3.9 k img/s after
+        # 13 GB of tensors were created and freed, no compute involved: tools/micro/infer_after_alloc.py), and
+        # one large region fares better than eighty medium ones
+        use_arena = os.environ.get("DISYOLO_ARENA", "1") != "0"
+        need = 0
+        for l in self.layers:
+            n = B * l.Ho * l.Wo * l.cout
+            tb = self.training and (not l.lock) and l.kind != "lin"
+            need += ((n * (4 if l.kind == "lin" else 2) + 255) // 256) * 256 * (2 if tb else 1)
+        self._act_arena = torch.zeros(need, dtype=torch.uint8, device=dev) if use_arena else None
+        cursor = [0]
+
+        def zeros4(b, h, w, c, dtype):
+            if self._act_arena is None:
+                return torch.zeros(b, h, w, c, dtype=dtype, device=dev)
+            nbytes = b * h * w * c * (4 if dtype == F32 else 2)
+            t = self._act_arena[cursor[0]:cursor[0] + nbytes].view(dtype).view(b, h, w, c)
+            cursor[0] += ((nbytes + 255) // 256) * 256
+            return t
+
         for l in self.layers:
             M = B * l.Ho * l.Wo
             train_bn = self.training and (not l.lock) and l.kind != "lin"
             if l.kind == "lin":
-                l.act = torch.zeros(B, l.Ho, l.Wo, l.cout, dtype=F32, device=dev)
+                l.act = zeros4(B, l.Ho, l.Wo, l.cout, F32)
             else:
-                l.act = torch.zeros(B, l.Ho, l.Wo, l.cout, dtype=BF16, device=dev)
-                l.raw = torch.zeros(B, l.Ho, l.Wo, l.cout, dtype=BF16, device=dev) if train_bn else None
+                l.act = zeros4(B, l.Ho, l.Wo, l.cout, BF16)
+                l.raw = zeros4(B, l.Ho, l.Wo, l.cout, BF16) if train_bn else None
             if l.idx > 1:
                 K = l.k * l.k * l.cin
                 l.wp = torch.zeros(l.cout, K, dtype=BF16, device=dev)
