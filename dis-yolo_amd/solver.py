@@ -74,7 +74,7 @@ class Solver(object):
     def __init__(self, net, data, evalu=None, val_data=None, output_dir: Optional[str] = None,
                  lr_schedule: str = "faithful", restore_weight: Optional[str] = None, stage: int = 1,
                  max_iter: Optional[int] = None, summary_iter: Optional[int] = None, save_iter: Optional[int] = None,
-                 log: Callable[[str], None] = print, use_program: bool = True):
+                 log: Callable[[str], None] = print, use_program: bool = True, shuffle_seed: Optional[int] = 20190530):
         """net: YOLONet(training=True); data: object with ``get()`` -> (images, true_masks, true_boxes, yolo_3,
         yolo_2, yolo_1, window) and attributes epoch / image_size / batch_size (utils/train_data.py:44-276);
         evalu: ``MAP``; val_data: object with ``get()`` -> (images [N,S,S,3], image ids, windows [N,4])
@@ -98,6 +98,10 @@ class Solver(object):
         self.log = log
         self.use_program = use_program
         self.global_step = 0
+        # tf.random_shuffle of the mask-loss RoIs every step (yolo/yolo3_net_pos.py:781-782): on the device, seeded
+        # (a net that already has a seed -- or injected permutations with shuffle_seed=None -- keeps it)
+        if net.shuffle_seed is None and shuffle_seed is not None:
+            net.shuffle_seed = shuffle_seed
         self.events = open(os.path.join(self.ckpt_dir, "events.jsonl"), "a")
         self.log("*** Train variables ***")
         for i, name in enumerate(net.trainable_names()):

@@ -134,7 +134,7 @@ def test_solver_train_loop_cadence_checkpoints_and_schedule(dev, tmp_path):
     nets = [YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=1, seed=4) for _ in range(3)]
     for n in nets:
         seeded_heads(n, 8)
-        n.shuffle_seed = 3
+    nets[1].shuffle_seed = nets[2].shuffle_seed = 20190530   # what the Solver gives a net that has none
     logs = []
     solver = Solver(nets[0], _TrainData(B, S), emap, _ValData(images, emap, S, dev), output_dir=str(tmp_path / "out"),
                     max_iter=20, summary_iter=2, save_iter=10, log=logs.append)
