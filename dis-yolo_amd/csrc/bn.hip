@@ -216,6 +216,54 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part,
   cC[c] = mean[c] * A - scale[c] * c1;
 }
 
+// ---- cross-rank batch statistics (SyncBN option of the data-parallel step) --------------
+// The two-stage reductions above are cut after their first stage: the partial rows of a column reduction are
+// summed to f64 per channel (local sums), the caller adds them up over the ranks (one small all-reduce), and
+// the finalize kernels below take the global sums and the global element count.
+template <int Q>
+__global__ __launch_bounds__(256) void partial_sums_kernel(const float* part, int rows, int C, double* sums) {
+  double r[Q];
+  int c;
+  if (!block_sum_partials<Q>(part, rows, C, r, &c)) return;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) sums[(size_t)c * Q + q] = r[q];
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_sums_kernel(const double* sums, int C, double inv_count, const float* gamma,
+                                                               const float* beta, float* mm, float* mv, float decay, float eps,
+                                                               float* scale, float* shift, float* mean_out, float* rstd_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = sums[2 * c] * inv_count;
+  double var = sums[2 * c + 1] * inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float meanf = (float)mean, varf = (float)var;
+  const float rstd = 1.0f / sqrtf(varf + eps);
+  const float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - meanf * sc;
+  if (mean_out) mean_out[c] = meanf;
+  if (rstd_out) rstd_out[c] = rstd;
+  if (mm) mm[c] = mm[c] * decay + meanf * (1.0f - decay);
+  if (mv) mv[c] = mv[c] * decay + varf * (1.0f - decay);
+}
+
+// dgamma / dbeta are this rank's own sums (the gradient exchange adds the ranks up later); the correction terms
+// of dx use the sums over ALL ranks
+__global__ __launch_bounds__(256) void bn_bwd_finalize_sums_kernel(const double* local, const double* global, int C,
+                                                                   double inv_count, const float* scale, const float* mean,
+                                                                   const float* rstd, float* dgamma, float* dbeta, float* cA,
+                                                                   float* cC) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] = (float)local[2 * c];
+  dgamma[c] = (float)local[2 * c + 1];
+  const float c1 = (float)(global[2 * c] * inv_count), c2 = (float)(global[2 * c + 1] * inv_count);
+  const float A = scale[c] * rstd[c] * c2;
+  cA[c] = A;
+  cC[c] = mean[c] * A - scale[c] * c1;
+}
+
 __device__ __forceinline__ void load8(const float* p, float* o) {
   const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
   o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = c.x; o[5] = c.y; o[6] = c.z; o[7] = c.w;
@@ -388,6 +436,81 @@ extern "C" int disyolo_bn_act_bwd(const void* dy, const void* x, const float* sc
   if (!(exp_bn() & 16))
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nvec)), dim3(256), 0, s, (const uint4*)dy, (const uint4*)x,
                      scale, shift, c1, c2, (uint4*)dx, nvec, C, alpha);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+// ---- SyncBN building blocks: the phases of bn_finalize / bn_act_bwd as separate calls, so the caller can add
+// the per-channel sums up over the data-parallel ranks between them (f64 [C][2], one all-reduce each) ----
+extern "C" int disyolo_bn_partial_sums(const float* partials, int rows, int C, double* sums, void* stream) {
+  DY_REQUIRE(partials && sums && rows > 0 && C > 0, "bn_partial_sums: bad args");
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_bn_partial_sums(partials, rows, C, sums, s); });
+  hipLaunchKernelGGL(partial_sums_kernel<2>, dim3(ceil_div(C, FIN_CPB)), dim3(256), 0, (hipStream_t)stream, partials, rows, C, sums);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+extern "C" int disyolo_bn_finalize_sums(const double* sums, int C, int64_t count, const float* gamma, const float* beta,
+                                        float* moving_mean, float* moving_var, float decay, float eps, float* scale,
+                                        float* shift, float* mean, float* rstd, void* stream) {
+  DY_REQUIRE(sums && gamma && beta && scale && shift && C > 0 && count > 0, "bn_finalize_sums: bad args");
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_bn_finalize_sums(sums, C, count, gamma, beta, moving_mean, moving_var, decay, eps, scale, shift, mean, rstd, s); });
+  hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, C,
+                     1.0 / (double)count, gamma, beta, moving_mean, moving_var, decay, eps, scale, shift, mean, rstd);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+extern "C" int disyolo_bn_bwd_reduce_rows(int64_t rows, int C) { return (rows > 0 && C > 0 && C % 8 == 0) ? colreduce_blocks(rows, C) : 0; }
+
+// first phase of bn_act_bwd: (sum g, sum g*xhat) partial rows -> this rank's f64 sums [C][2]
+extern "C" int disyolo_bn_bwd_reduce(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
+                                     const float* rstd, int64_t rows, int C, float alpha, double* sums, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  DY_REQUIRE(dy && x && scale && shift && mean && rstd && sums && rows > 0 && C > 0 && C % 8 == 0, "bn_bwd_reduce: bad args");
+  const int nb = colreduce_blocks(rows, C), rpb = colreduce_rpb(rows, C);
+  if (!workspace || workspace_bytes < (size_t)nb * C * 2 * sizeof(float)) {
+    disyolo_set_error("bn_bwd_reduce: workspace too small");
+    return DISYOLO_E_WORKSPACE;
+  }
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_bn_bwd_reduce(dy, x, scale, shift, mean, rstd, rows, C, alpha, sums, workspace, workspace_bytes, s); });
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = C / 8, cpb = chunks < 256 ? chunks : 256;
+  float* part = (float*)workspace;
+  hipLaunchKernelGGL(colreduce_kernel<1>, dim3(nb, ceil_div(chunks, cpb)), dim3(256), 0, s, (const uint4*)dy, (const uint4*)x,
+                     scale, shift, mean, rstd, alpha, rows, C, rpb, part);
+  DY_CHECK_LAUNCH();
+  hipLaunchKernelGGL(partial_sums_kernel<2>, dim3(ceil_div(C, FIN_CPB)), dim3(256), 0, s, (const float*)part, nb, C, sums);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+// second phase: dgamma/dbeta from this rank's sums, dx with the correction terms of the sums over all ranks
+// (`count` = rows over all ranks); cA/cC scratch: 2*C floats of workspace
+extern "C" int disyolo_bn_bwd_apply_sums(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
+                                         const float* rstd, const double* local_sums, const double* global_sums, int64_t count,
+                                         void* dx, float* dgamma, float* dbeta, int64_t rows, int C, float alpha, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  DY_REQUIRE(dy && x && scale && shift && mean && rstd && local_sums && global_sums && dx && dgamma && dbeta,
+             "bn_bwd_apply_sums: null pointer");
+  DY_REQUIRE(rows > 0 && count >= rows && C > 0 && C % 8 == 0, "bn_bwd_apply_sums: bad shape");
+  if (!workspace || workspace_bytes < 2 * (size_t)C * sizeof(float)) {
+    disyolo_set_error("bn_bwd_apply_sums: workspace too small");
+    return DISYOLO_E_WORKSPACE;
+  }
+  DY_RECORD_OR_RUN([=](void* s) {
+    return disyolo_bn_bwd_apply_sums(dy, x, scale, shift, mean, rstd, local_sums, global_sums, count, dx, dgamma, dbeta, rows, C,
+                                     alpha, workspace, workspace_bytes, s);
+  });
+  hipStream_t s = (hipStream_t)stream;
+  float* c1 = (float*)workspace;
+  float* c2 = c1 + C;
+  hipLaunchKernelGGL(bn_bwd_finalize_sums_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, local_sums, global_sums, C,
+                     1.0 / (double)count, scale, mean, rstd, dgamma, dbeta, c1, c2);
+  DY_CHECK_LAUNCH();
+  const int64_t nvec = rows * C / 8;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nvec)), dim3(256), 0, s, (const uint4*)dy, (const uint4*)x, scale, shift,
+                     c1, c2, (uint4*)dx, nvec, C, alpha);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }

@@ -162,12 +162,18 @@ def broadcast_parameters(net, src: int = 0, process_group=None) -> None:
 
 
 def enable_data_parallel(net, process_group=None, bucket_mb: float = 12.0, wire: Optional[str] = None,
-                         algo: Optional[str] = None, broadcast: bool = True) -> GradientAllReduce:
+                         algo: Optional[str] = None, broadcast: bool = True, sync_bn: bool = False) -> GradientAllReduce:
     """wire / algo default to DISYOLO_DP_WIRE / DISYOLO_DP_ALGO (f32 / allreduce).  ``broadcast``: every
-    rank starts from rank 0's variables (the reference has one process, hence one initialisation)."""
+    rank starts from rank 0's variables (the reference has one process, hence one initialisation).
+    ``sync_bn``: batch-norm statistics (forward moments and the two backward sums) over all ranks' batches,
+    so that N ranks x b images train like one process with N*b images."""
     wire = wire or os.environ.get("DISYOLO_DP_WIRE", "f32")
     algo = algo or os.environ.get("DISYOLO_DP_ALGO", "allreduce")
     net.dp = GradientAllReduce(net, process_group, bucket_mb, wire, algo)
     if broadcast and net.dp.world_size > 1:
         broadcast_parameters(net, 0, process_group)
+    if sync_bn:
+        # batch-norm statistics over the global batch (SURVEY.md 8e: optional, default local): two all-reduces of
+        # [C,2] f64 sums per trainable batch-norm layer and step, on the forward / backward critical chain
+        net.enable_sync_bn()
     return net.dp

@@ -74,6 +74,14 @@ _SIGS = {
     "disyolo_bn_fold": (C.c_int, [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 2 + [C.c_int, C.c_void_p]),
     "disyolo_bn_act_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_float, C.c_void_p]),
     "disyolo_bn_act_bwd_workspace": (C.c_size_t, [C.c_int64, C.c_int]),
+    "disyolo_bn_partial_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "disyolo_bn_finalize_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int64] + [C.c_void_p] * 4 + [C.c_float, C.c_float] +
+                                 [C.c_void_p] * 5),
+    "disyolo_bn_bwd_reduce_rows": (C.c_int, [C.c_int64, C.c_int]),
+    "disyolo_bn_bwd_reduce": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t,
+                                        C.c_void_p]),
+    "disyolo_bn_bwd_apply_sums": (C.c_int, [C.c_void_p] * 8 + [C.c_int64] + [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_float,
+                                            C.c_void_p, C.c_size_t, C.c_void_p]),
     "disyolo_bn_act_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t,
                                                        C.c_void_p]),
     "disyolo_upsample2x_bwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 7 + [C.c_void_p]),
@@ -212,10 +220,14 @@ class CmdList:
         if TIMER is not None:
             raise DisyoloError("cannot record a command list while the kernel timer is active")
         _check(load().disyolo_cmdlist_begin(self.h), "cmdlist_begin")
+        global CURRENT_LANE
+        CURRENT_LANE = 0
         return self
 
     def __exit__(self, *exc):
         _check(load().disyolo_cmdlist_end(), "cmdlist_end")
+        global CURRENT_LANE
+        CURRENT_LANE = 0
         return False
 
     def size(self) -> int:
@@ -543,6 +555,33 @@ def colstats(x, stats, rows, C_) -> None:
     _check(load().disyolo_colstats(_p(x), _p(stats), rows, C_, _stream()), "colstats")
 
 
+def bn_partial_sums(partials, rows, C_, sums) -> None:
+    """SyncBN: conv-epilogue partial rows -> this rank's f64 sums [C,2]"""
+    _need(sums, torch.float64, "sums")
+    _check(load().disyolo_bn_partial_sums(_p(partials), rows, C_, _p(sums), _stream()), "bn_partial_sums")
+
+
+def bn_finalize_sums(sums, C_, count, gamma, beta, mm, mv, decay, eps, scale, shift, mean, rstd) -> None:
+    _need(sums, torch.float64, "sums")
+    _check(load().disyolo_bn_finalize_sums(_p(sums), C_, count, _p(gamma), _p(beta), _p(mm), _p(mv), decay, eps, _p(scale),
+                                           _p(shift), _p(mean), _p(rstd), _stream()), "bn_finalize_sums")
+
+
+def bn_bwd_reduce(dy, x, scale, shift, mean, rstd, rows, C_, sums, ws: Workspace, alpha=0.1) -> None:
+    _need(sums, torch.float64, "sums")
+    buf = ws.get(load().disyolo_bn_bwd_reduce_rows(rows, C_) * C_ * 2 * 4)
+    _check(load().disyolo_bn_bwd_reduce(_p(dy), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), rows, C_, alpha, _p(sums),
+                                        _p(buf), buf.numel(), _stream()), "bn_bwd_reduce")
+
+
+def bn_bwd_apply_sums(dy, x, scale, shift, mean, rstd, local_sums, global_sums, count, dx, dgamma, dbeta, rows, C_,
+                      ws: Workspace, alpha=0.1) -> None:
+    buf = ws.get(2 * C_ * 4)
+    _check(load().disyolo_bn_bwd_apply_sums(_p(dy), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(local_sums),
+                                            _p(global_sums), count, _p(dx), _p(dgamma), _p(dbeta), rows, C_, alpha, _p(buf),
+                                            buf.numel(), _stream()), "bn_bwd_apply_sums")
+
+
 def bn_fold(gamma, beta, mm, mv, eps, scale, shift) -> None:
     _check(load().disyolo_bn_fold(_p(gamma), _p(beta), _p(mm), _p(mv), eps, _p(scale), _p(shift), gamma.numel(),
                                   _stream()), "bn_fold")
@@ -692,8 +731,13 @@ def adam_step(w, grad, m, v, n, n_decay, lr, b1, b2, eps, l2, t, grad_scale=1.0)
                                     _stream()), "adam_step")
 
 
+CURRENT_LANE = 0     # lane the recording thread's launches go to (mirrors the executor's state)
+
+
 def set_lane(lane: int) -> None:
+    global CURRENT_LANE
     _check(load().disyolo_cmdlist_set_lane(lane), "cmdlist_set_lane")
+    CURRENT_LANE = lane
 
 
 def lane_sync(src: int, dst: int) -> None:

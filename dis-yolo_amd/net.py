@@ -34,7 +34,7 @@ class Layer:
                  "Wo", "w", "bias", "gamma", "beta", "mm", "mv", "scale", "shift", "mean", "rstd", "wp", "wdg", "raw",
                  "act", "stats", "stats_rows", "desc", "grad", "grad_set", "need_grad", "dw", "dbias", "dgamma",
                  "dbeta", "dx", "pad_t", "pad_l", "dgrad_descs", "wgrad_desc", "cout_pad",
-                 "act8", "w8", "s_w", "s_out", "escale", "desc8", "dual16")
+                 "act8", "w8", "s_w", "s_out", "escale", "desc8", "dual16", "bn_sums", "bwd_local", "bwd_global")
 
     def __init__(self, idx, cin, cout, k, stride, kind, src, src_up=None, shortcut=None):
         self.idx, self.cin, self.cout, self.k, self.stride, self.kind = idx, cin, cout, k, stride, kind
@@ -169,6 +169,8 @@ class YOLONet(object):
         self._lr = float(cfg.LEARNING_RATE)
         self.lr_dev = None       # device copy read by the optimizer kernel (set in _init_params)
         self.dp = None  # set by enable_data_parallel
+        self.sync_bn = False    # enable_data_parallel(sync_bn=True): batch statistics over all ranks
+        self._rec = None        # (list, cut points) while a step is being recorded
         self._prog = None       # recorded command list of one training step
         self._prog_marks = []   # [(command index, layer)] all-reduce trigger points
         self._graph = None      # hipGraph of the recorded step (single GPU)
@@ -606,8 +608,7 @@ class YOLONet(object):
             if train_bn:
                 L.conv_first_fwd(self.images, l.w, self._ones32, self._zeros32, l.raw, alpha=1.0)
                 L.colstats(l.raw, l.stats, M, l.cout)
-                L.bn_finalize(l.stats, l.stats_rows, l.cout, M, l.gamma, l.beta, l.mm, l.mv, cfg.BN_DECAY,
-                              cfg.BN_EPSILON, l.scale, l.shift, l.mean, l.rstd)
+                self._bn_finalize(l, M)
                 L.bn_act_fwd(l.raw, l.scale, l.shift, None, l.act, M, l.cout, cfg.ALPHA)
             else:
                 if not l.lock and self.training:
@@ -618,8 +619,7 @@ class YOLONet(object):
             L.conv2d_fwd(l.desc)
         elif train_bn:
             L.conv2d_fwd(l.desc)                       # raw conv + per-channel partial sums
-            L.bn_finalize(l.stats, l.stats_rows, l.cout, M, l.gamma, l.beta, l.mm, l.mv, cfg.BN_DECAY,
-                          cfg.BN_EPSILON, l.scale, l.shift, l.mean, l.rstd)
+            self._bn_finalize(l, M)
             L.bn_act_fwd(l.raw, l.scale, l.shift, res, l.act, M, l.cout, cfg.ALPHA)
         else:
             if self.training and not l.lock:
@@ -631,6 +631,41 @@ class YOLONet(object):
                 L.conv2d_fwd(d)
             else:
                 L.conv2d_fwd(l.desc)
+
+    def _bn_finalize(self, l, M: int) -> None:
+        """batch statistics -> scale/shift/mean/rstd + moving statistics (yolo/yolo3_net_pos.py:90-98).  With
+        SyncBN the per-channel sums are added up over the data-parallel ranks first (SURVEY.md 8e option)."""
+        if not self.sync_bn:
+            L.bn_finalize(l.stats, l.stats_rows, l.cout, M, l.gamma, l.beta, l.mm, l.mv, cfg.BN_DECAY,
+                          cfg.BN_EPSILON, l.scale, l.shift, l.mean, l.rstd)
+            return
+        L.bn_partial_sums(l.stats, l.stats_rows, l.cout, l.bn_sums)
+        self._sync_sums(l.bn_sums)
+        L.bn_finalize_sums(l.bn_sums, l.cout, M * self.dp.world_size, l.gamma, l.beta, l.mm, l.mv, cfg.BN_DECAY,
+                           cfg.BN_EPSILON, l.scale, l.shift, l.mean, l.rstd)
+
+    def _sync_sums(self, t: torch.Tensor) -> None:
+        """all-reduce(SUM) of a small f64 tensor over the ranks, ordered on the lane that produced it: issued
+        directly in the per-call path, a cut point of the recorded list otherwise (run_program issues it)"""
+        if self._rec is not None:
+            prog, marks = self._rec
+            marks.append((prog.size(), ("sync", t, L.CURRENT_LANE)))
+        else:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.dp.pg)
+
+    def enable_sync_bn(self) -> None:
+        """called by enable_data_parallel(sync_bn=True)"""
+        if self.dp is None:
+            raise L.DisyoloError("SyncBN needs data parallelism (enable_data_parallel)")
+        if self._prog is not None:
+            raise L.DisyoloError("enable SyncBN before build_program()")
+        for l in self.layers:
+            if self.training and not l.lock and l.kind != "lin":
+                l.bn_sums = torch.zeros(l.cout, 2, dtype=torch.float64, device=self.device)
+                l.bwd_local = torch.zeros(l.cout, 2, dtype=torch.float64, device=self.device)
+                l.bwd_global = torch.zeros(l.cout, 2, dtype=torch.float64, device=self.device)
+        self.sync_bn = True
 
     def _detect(self, det_thresh: float) -> None:
         L.detect(self.by_idx[75].act, self.by_idx[67].act, self.by_idx[59].act, self.B, self.S, self.num_class,
@@ -827,8 +862,17 @@ class YOLONet(object):
             else:
                 if not l.grad_set:
                     raise L.DisyoloError("layer %d received no gradient" % l.idx)
-                L.bn_act_bwd(l.grad, l.raw, l.scale, l.shift, l.mean, l.rstd, l.dx, l.dgamma, l.dbeta, M, l.cout,
-                             self.ws, cfg.ALPHA)
+                if self.sync_bn:
+                    # (sum g, sum g*xhat) of this rank -> the same over all ranks -> dx; dgamma / dbeta stay local
+                    L.bn_bwd_reduce(l.grad, l.raw, l.scale, l.shift, l.mean, l.rstd, M, l.cout, l.bwd_local, self.ws, cfg.ALPHA)
+                    L.copy2d_f32(l.bwd_local.view(torch.float32), l.bwd_global.view(torch.float32), 1, 4 * l.cout,
+                                 4 * l.cout, 4 * l.cout)
+                    self._sync_sums(l.bwd_global)
+                    L.bn_bwd_apply_sums(l.grad, l.raw, l.scale, l.shift, l.mean, l.rstd, l.bwd_local, l.bwd_global,
+                                        M * self.dp.world_size, l.dx, l.dgamma, l.dbeta, M, l.cout, self.ws, cfg.ALPHA)
+                else:
+                    L.bn_act_bwd(l.grad, l.raw, l.scale, l.shift, l.mean, l.rstd, l.dx, l.dgamma, l.dbeta, M, l.cout,
+                                 self.ws, cfg.ALPHA)
                 dx, ld = l.dx, l.cout
                 if l.shortcut is not None:
                     sc = self.by_idx[l.shortcut]
@@ -1110,6 +1154,9 @@ class YOLONet(object):
             os.environ.setdefault("DISYOLO_LANE1_LOW", "0")
         prog = L.CmdList()
         marks = []
+        if self.sync_bn and parity is not None:
+            raise L.DisyoloError("SyncBN is not wired for the pipelined-backbone step")
+        self._rec = (prog, marks) if self.dp is not None else None
         with prog:
             first = 1
             if parity is not None:
@@ -1141,6 +1188,7 @@ class YOLONet(object):
             else:
                 self.backward(sweep=True)
             bwd_end = prog.size()
+            self._rec = None
             self.optimizer_step(1.0 / self.dp.world_size if self.dp is not None else 1.0)
         return prog, marks, bwd_end
 
@@ -1161,11 +1209,18 @@ class YOLONet(object):
         if side is None:
             side = self._side_streams[id(self._prog)] = self._prog.side_stream(self.device)
         pos, first = 0, True
-        for idx, bucket in self._prog_marks:
+        for idx, what in self._prog_marks:
             self._prog.run(pos, idx, fork=first, join=False)
             first = False
-            with torch.cuda.stream(side if self.use_side_lane else torch.cuda.current_stream()):
-                self.dp.fire(bucket)
+            if isinstance(what, tuple):
+                # SyncBN: the per-channel sums of one layer, on the lane that produced them
+                _, t, lane = what
+                with torch.cuda.stream(side if (lane == 1 and self.use_side_lane) else torch.cuda.current_stream()):
+                    import torch.distributed as dist
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.dp.pg)
+            else:
+                with torch.cuda.stream(side if self.use_side_lane else torch.cuda.current_stream()):
+                    self.dp.fire(what)
             pos = idx
         self._prog.run(pos, self._bwd_end, fork=first, join=True)
         self.dp.finish()

@@ -168,6 +168,25 @@ int disyolo_bn_finalize(const float* stats, int rows, int C, int64_t count, cons
                         const float* beta, float* moving_mean, float* moving_var, float decay,
                         float eps, float* scale, float* shift, float* mean, float* rstd,
                         void* stream);
+/* SyncBN building blocks (data-parallel option; the reference is single-GPU): the phases of
+ * bn_finalize / bn_act_bwd as separate calls, so that a caller can add the per-channel f64 sums [C][2] up over
+ * the ranks (one small all-reduce) between them.  Forward: conv partials -> bn_partial_sums -> (all-reduce) ->
+ * bn_finalize_sums(count = elements per channel over ALL ranks).  Backward: bn_bwd_reduce -> (all-reduce of a
+ * copy) -> bn_bwd_apply_sums: dgamma/dbeta stay this rank's sums (the gradient exchange adds the ranks up), dx
+ * uses the global ones.  With one rank and no all-reduce the results equal bn_finalize / bn_act_bwd. */
+int disyolo_bn_partial_sums(const float* partials, int rows, int C, double* sums, void* stream);
+int disyolo_bn_finalize_sums(const double* sums, int C, int64_t count, const float* gamma, const float* beta,
+                             float* moving_mean, float* moving_var, float decay, float eps, float* scale,
+                             float* shift, float* mean, float* rstd, void* stream);
+int disyolo_bn_bwd_reduce_rows(int64_t rows, int C);   /* workspace of bn_bwd_reduce: rows x C x 2 floats */
+int disyolo_bn_bwd_reduce(const void* dy, const void* x, const float* scale, const float* shift,
+                          const float* mean, const float* rstd, int64_t rows, int C, float alpha, double* sums,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int disyolo_bn_bwd_apply_sums(const void* dy, const void* x, const float* scale, const float* shift,
+                              const float* mean, const float* rstd, const double* local_sums,
+                              const double* global_sums, int64_t count, void* dx, float* dgamma, float* dbeta,
+                              int64_t rows, int C, float alpha, void* workspace, size_t workspace_bytes,
+                              void* stream);
 /* (sum, sum of squares) partials of a materialised bf16 [rows,C] conv output, in the layout
  * bn_finalize consumes: stats f32 [disyolo_colstats_rows(rows,C)][C][2] */
 int disyolo_colstats_rows(int64_t rows, int C);

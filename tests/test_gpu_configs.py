@@ -256,6 +256,34 @@ def test_config2_wire_formats_and_reduce_scatter_variant(dev, one_rank_rccl, wir
         assert float(dw.max()) < 0.5 * cfg.LEARNING_RATE, info
 
 
+def test_sync_bn_on_one_rank_is_the_plain_step(dev, one_rank_rccl):
+    """SyncBN with a single rank: the all-reduces are identities, the statistics go through the split
+    (partial rows -> f64 sums -> finalize) kernels instead of the fused ones -- same arithmetic, so the
+    recorded step must reproduce the plain step bit for bit (eager and recorded)."""
+    from disyolo_amd.dp import enable_data_parallel
+    B, S = 2, 64
+    batch = O.synthetic_batch(B, S, seed=72)
+    nets = [YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=2, seed=3) for _ in range(3)]
+    for n in nets:
+        seeded_heads(n, 31, gain=6.0, bias_std=0.5)
+        n.shuffle_seed = 5
+        n.set_batch(batch)
+    plain, sync_eager, sync_prog = nets
+    enable_data_parallel(sync_eager, bucket_mb=4.0, sync_bn=True)
+    enable_data_parallel(sync_prog, bucket_mb=4.0, sync_bn=True)
+    plain.build_program(det_thresh=0.1)
+    sync_prog.build_program(det_thresh=0.1)
+    assert any(isinstance(w, tuple) for _, w in sync_prog._prog_marks)       # the recorded list is cut at the statistics
+    for _ in range(2):
+        ls = [float(n.train_step(None, det_thresh=0.1).cpu()) for n in (plain, sync_eager, sync_prog)]
+        assert ls[0] == ls[1] == ls[2]
+    torch.cuda.synchronize()
+    for n in (sync_eager, sync_prog):
+        assert torch.equal(n.arena, plain.arena) and torch.equal(n.adam_v, plain.adam_v)
+        for name in plain.params:
+            assert torch.equal(n.params[name], plain.params[name]), name
+
+
 def test_bf16_gradient_storage_along_the_residual_trunk(dev):
     """Stage 2, 192x192, B=2: weight gradients of conv1-10 (the far end of 23 residual blocks whose
     trunk gradient is rounded to bf16 once per block) and of conv43-52 (the near end) against the oracle

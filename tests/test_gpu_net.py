@@ -266,6 +266,68 @@ def test_bn_act_bwd_matches_f64_and_is_deterministic(dev, rows, Cc):
         assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
 
 
+def test_sync_bn_phases_over_two_halves_equal_the_whole(dev):
+    """The SyncBN building blocks on one GPU: a [rows, C] tensor cut into two 'ranks'.  Each half reduces its
+    own partial rows to f64 sums; the sums added up (what the all-reduce does) and finalised with the global
+    count give the moments bn_finalize computes over the whole tensor; in the backward pass the halves' dx with the
+    global sums equal bn_act_bwd's dx over the whole tensor, and the halves' dgamma / dbeta add up to the whole's."""
+    g0 = torch.Generator().manual_seed(11)
+    rows, C = 2 * 1536, 64
+    x = (torch.randn(rows, C, generator=g0) * 1.7 + 0.4).to(torch.bfloat16).to(dev)
+    dy = torch.randn(rows, C, generator=g0).to(torch.bfloat16).to(dev)
+    gamma = (torch.rand(C, generator=g0) + 0.5).to(dev)
+    beta = (torch.randn(C, generator=g0) * 0.2).to(dev)
+    ws = L.Workspace(dev)
+    f = lambda: torch.zeros(C, device=dev)
+
+    def whole():
+        nrows = L.colstats_rows(rows, C)
+        stats = torch.zeros(nrows, C, 2, device=dev)
+        L.colstats(x, stats, rows, C)
+        mm, mv, sc, sh, mu, rs = f(), torch.ones(C, device=dev), f(), f(), f(), f()
+        L.bn_finalize(stats, nrows, C, rows, gamma, beta, mm, mv, 0.997, 1e-5, sc, sh, mu, rs)
+        dx, dg, db = torch.empty_like(x), f(), f()
+        L.bn_act_bwd(dy, x, sc, sh, mu, rs, dx, dg, db, rows, C, ws, 0.1)
+        return mm, mv, sc, sh, mu, rs, dx, dg, db
+
+    want = whole()
+    h = rows // 2
+    sums = []
+    for r in range(2):
+        xs = x[r * h:(r + 1) * h]
+        nrows = L.colstats_rows(h, C)
+        stats = torch.zeros(nrows, C, 2, device=dev)
+        L.colstats(xs, stats, h, C)
+        s = torch.zeros(C, 2, dtype=torch.float64, device=dev)
+        L.bn_partial_sums(stats, nrows, C, s)
+        sums.append(s)
+    tot = sums[0] + sums[1]
+    mm, mv, sc, sh, mu, rs = f(), torch.ones(C, device=dev), f(), f(), f(), f()
+    L.bn_finalize_sums(tot, C, rows, gamma, beta, mm, mv, 0.997, 1e-5, sc, sh, mu, rs)
+    torch.cuda.synchronize()
+    for got, w in zip((mm, mv, sc, sh, mu, rs), want[:6]):
+        np.testing.assert_allclose(got.cpu().numpy(), w.cpu().numpy(), rtol=2e-6, atol=1e-7)
+    # backward with the whole-tensor moments (so that only the backward phases are compared)
+    sc, sh, mu, rs = want[2:6]
+    loc = []
+    for r in range(2):
+        s = torch.zeros(C, 2, dtype=torch.float64, device=dev)
+        L.bn_bwd_reduce(dy[r * h:(r + 1) * h], x[r * h:(r + 1) * h], sc, sh, mu, rs, h, C, s, ws, 0.1)
+        loc.append(s)
+    glob = loc[0] + loc[1]
+    dxs, dgs, dbs = [], [], []
+    for r in range(2):
+        dx, dg, db = torch.empty(h, C, dtype=torch.bfloat16, device=dev), f(), f()
+        L.bn_bwd_apply_sums(dy[r * h:(r + 1) * h], x[r * h:(r + 1) * h], sc, sh, mu, rs, loc[r], glob, rows, dx, dg, db, h, C, ws, 0.1)
+        dxs.append(dx), dgs.append(dg), dbs.append(db)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose((dgs[0] + dgs[1]).cpu().numpy(), want[7].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose((dbs[0] + dbs[1]).cpu().numpy(), want[8].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    got_dx, want_dx = torch.cat(dxs).float().cpu(), want[6].float().cpu()
+    assert float((got_dx - want_dx).abs().max()) <= 2.0 ** -7 * float(want_dx.abs().max())
+    assert float((got_dx != want_dx).float().mean()) < 1e-3       # the f32 correction terms differ in the last bit at most
+
+
 def test_adam_three_step_trace(dev):
     """TF-form Adam known-answer trace: epsilon outside the bias correction."""
     w = torch.tensor([1.0, -2.0, 0.5, 3.0], device=dev)
