@@ -4,6 +4,7 @@
 //
 // Replaces tf.nn.moments / tf.nn.batch_normalization / tf.assign(moving stats) /
 // tf.maximum(alpha*x, x) and their TF-autodiff gradients, yolo/yolo3_net_pos.py:68-107.
+#include <stdio.h>
 #include <stdlib.h>
 #include "common.h"
 #include "runtime.h"
@@ -332,7 +333,11 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const bf16* src, bf
 // DISYOLO_EXP_BN (timing experiment, results are wrong): bit 0 skip the forward finalize, 1 the forward apply,
 // 2 the backward column reduction, 3 the backward finalize, 4 the backward apply
 int exp_bn() {
-  static const int v = getenv("DISYOLO_EXP_BN") ? atoi(getenv("DISYOLO_EXP_BN")) : 0;
+  static const int v = [] {
+    const int e = getenv("DISYOLO_EXP_BN") ? atoi(getenv("DISYOLO_EXP_BN")) : 0;
+    if (e) fprintf(stderr, "disyolo: DISYOLO_EXP_BN=%d -- batch-norm kernels are skipped / doubled, RESULTS ARE WRONG (timing experiment)\n", e);
+    return e;
+  }();
   return v;
 }
 int grid_for(int64_t n) {

@@ -18,6 +18,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import math
 import json
 import os
+import sys
 import numpy as np
 import torch
 
@@ -178,6 +179,8 @@ class YOLONet(object):
         self._side_streams = {}  # id(recorded list) -> its side lane as a torch stream
         self._progs = None      # [parity] -> (list, marks, bwd_end) of the pipelined step
         self.use_side_lane = os.environ.get("DISYOLO_SIDE_LANE", "1") != "0"
+        if os.environ.get("DISYOLO_EXP_SKIP_WGRAD") in ("1", "2"):
+            print("disyolo: DISYOLO_EXP_SKIP_WGRAD is set -- weight gradients are NOT computed (timing experiment)", file=sys.stderr)
         # weight gradients of the last layers of the backward pass stay on the main lane (tuned below)
         self.tail_on_main = int(os.environ.get("DISYOLO_TAIL_MAIN", "0"))
         self._init_params(seed, xavier_locked)
