@@ -937,12 +937,14 @@ Patch pick_patch(int H, int W, int max_frags, int max_halo) {
   return best;
 }
 // halo tile ids: 16 = 8 waves x 3 fragments (up to 384 pixels: 18x18), 17 = 4 waves x 3
-// (up to 192 pixels: 9x18); both 64 output channels per block
+// (up to 192 pixels: 9x18), both 64 output channels per block; 18 = as 16 with 32 output channels per block
+// (twice the blocks: the 18x18 maps, one patch per image, then give 256 blocks at 1024 channels)
 bool halo_cfg(int id, int& nw, int& fw) {
-  if (id == 16) { nw = 8; fw = 3; return true; }
+  if (id == 16 || id == 18) { nw = 8; fw = 3; return true; }
   if (id == 17) { nw = 4; fw = 3; return true; }
   return false;
 }
+int halo_bn(int id) { return id == 18 ? 32 : 64; }
 bool halo_ok(const disyolo_conv_desc* d, int id, Patch* out) {
   int nw, fw;
   if (!halo_cfg(id, nw, fw)) return false;
@@ -1152,7 +1154,7 @@ extern "C" int disyolo_conv2d_tile(const disyolo_conv_desc* d, int* bm, int* bn,
     Patch pt;
     if (halo_ok(d, sel & 0xff, &pt)) {
       if (bm) *bm = pt.ph * pt.pw;
-      if (bn) *bn = 64;
+      if (bn) *bn = halo_bn(sel & 0xff);
       if (bk) *bk = 32;
       if (stages) *stages = 2;
       return sel & 0xff;
@@ -1209,7 +1211,8 @@ extern "C" int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream) {
   if ((sel & 0xff) >= 16) {
     Patch pt;
     if (halo_ok(d, sel & 0xff, &pt))
-      return (sel & 0xff) == 16 ? launch_halo<8, 3, 4>(p, pt, s) : launch_halo<4, 3, 4>(p, pt, s);
+      return (sel & 0xff) == 16 ? launch_halo<8, 3, 4>(p, pt, s)
+             : (sel & 0xff) == 18 ? launch_halo<8, 3, 2>(p, pt, s) : launch_halo<4, 3, 4>(p, pt, s);
     sel = pick_auto(d, p.M);   // shape not covered by the patch kernel
   }
   const bool bk64 = (d->C0 % 64 == 0) && (d->C1 % 64 == 0) && !(sel & 0x100);

@@ -65,7 +65,8 @@ typedef struct disyolo_conv_desc {
                              tuner pins (what YOLONet.autotune does): low byte = id
                              (1-12 GEMM block tiles 64x64 ... 256x128, 13-15 the same
                              with two K groups per block, 16/17 the 3x3 stride-1 patch
-                             kernel with 8/4 waves; an id that does not cover the shape
+                             kernel with 8/4 waves, 18 = 16 with 32 instead of 64 output
+                             channels per block; an id that does not cover the shape
                              falls back), bit 8 = force K depth 32, bit 9 = the tile's
                              alternative pipeline depth                              */
   const void* x0;         /* bf16 [B,H,W,C0]                                          */

@@ -81,6 +81,8 @@ CASES = [
     (2, 20, 24, 96, 64, 3, 1, 16),         # 20x12 patches, three K slices
     (1, 20, 20, 32, 64, 3, 2, 16),         # stride 2: not covered, falls back to the GEMM kernel
     (3, 9, 9, 256, 256, 3, 1, 16),         # 9x9 patch = whole image, 6 of 24 fragment slots used
+    (2, 18, 18, 64, 128, 3, 1, 18),        # patch kernel, 32 output channels per block
+    (1, 18, 18, 96, 72, 3, 1, 18),         # ... ragged channel tile (72 = 2 x 32 + 8), three K slices
 ]
 
 
@@ -133,7 +135,7 @@ def test_conv_out_f32_bias_small_n(dev):
         check(y, want, 1e-5, 1e-4 * float(want.abs().max()))
 
 
-@pytest.mark.parametrize("tile", [16, 17])
+@pytest.mark.parametrize("tile", [16, 17, 18])
 def test_conv_halo_residual_f32_and_pads(dev, tile):
     """patch kernel epilogue variants: residual add, f32 output with bias, and the data-gradient
     use (explicit pads, accumulate into an existing gradient through the residual pointer)"""

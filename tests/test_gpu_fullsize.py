@@ -130,7 +130,7 @@ def test_conv_kernel_families_agree_at_full_size(dev, H, Cin, Cout):
     scale = torch.full((Cout,), 2.0 ** -9, device=dev)
     shift = torch.full((Cout,), 0.25, device=dev)
     outs_f32, outs_bf16 = [], []
-    for tile in (3, 6, 10, 12, 0x20d, 14, 16, 17):
+    for tile in (3, 6, 10, 12, 0x20d, 14, 16, 17, 18):
         y = torch.empty(B, H, H, Cout, dtype=torch.float32, device=dev)
         L.conv2d_fwd(L.make_conv_desc(x, w, y, 3, 1, out_f32=True, tile=tile))
         yb = torch.empty(B, H, H, Cout, dtype=torch.bfloat16, device=dev)
