@@ -45,6 +45,8 @@ _SIGS = {
     "disyolo_version": (C.c_int, []),
     "disyolo_last_error": (C.c_char_p, []),
     "disyolo_conv_desc_size": (C.c_size_t, []),
+    "disyolo_find_contours": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "disyolo_conv2d_stats_rows": (C.c_int, [C.POINTER(ConvDesc)]),
     "disyolo_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "disyolo_conv2d_tile": (C.c_int, [C.POINTER(ConvDesc)] + [C.POINTER(C.c_int)] * 4),

@@ -80,6 +80,15 @@ typedef struct disyolo_conv_desc {
   float* stats;           /* f32 [disyolo_conv2d_stats_rows][Cout][2] or NULL         */
 } disyolo_conv_desc;
 
+/* Host-side (no device work): the contour extraction of the dataset pre-processing, cv2.findContours(img,
+ * cv2.RETR_TREE, cv2.CHAIN_APPROX_NONE) of pre_process.py:78-86 -- Suzuki-Abe border following, OpenCV's point
+ * order and contour numbering (cv2 not available in the build environment: parity unpinned).  binary: h x w bytes,
+ * non-zero = foreground.  points_xy int32 [n_points][2] (x, y); contour_start int32 [n_contours + 1]; hierarchy
+ * int32 [n_contours][4] = next, previous, first child, parent.  Too-small buffers: DISYOLO_E_WORKSPACE with the
+ * needed sizes in *n_contours / *n_points (call once with max 0 to size them). */
+int disyolo_find_contours(const uint8_t* binary, int h, int w, int32_t* points_xy, int64_t max_points,
+                          int32_t* contour_start, int32_t* hierarchy, int max_contours, int* n_contours,
+                          int64_t* n_points);
 /* sizeof(disyolo_conv_desc) as this library was built: a binding checks its mirror against it */
 size_t disyolo_conv_desc_size(void);
 /* rows of the `stats` partial buffer a call with this descriptor writes */

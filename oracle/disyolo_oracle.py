@@ -1115,3 +1115,204 @@ def motion_blur3(img: np.ndarray, angle: int, line_type: int) -> np.ndarray:
         if use:
             out = out + pad[1 - dy:1 - dy + S, 1 - dx:1 - dx + S] * w
     return np.clip(out.astype(np.int64), 0, 255).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------
+# dataset pre-processing (pre_process.py:16-318): mask image -> contours -> regions
+# ---------------------------------------------------------------------------
+# The contour extraction is OpenCV's, not the reference's own code: cv2.findContours(thresh, cv2.RETR_TREE,
+# cv2.CHAIN_APPROX_NONE) (pre_process.py:78,82,86; OpenCV 3.x API: three return values; version unpinned,
+# "opencv-python" in the README).  cv2 is installed in neither interpreter of the build container, so this is
+# a restatement of the published algorithm it implements -- S. Suzuki, K. Abe, "Topological structural
+# analysis of digitized binary images by border following", CVGIP 30 (1985), Algorithm 1 -- with the
+# conventions of OpenCV's legacy implementation as far as they are documented / observable:
+#   * foreground 8-connected, raster scan with a one-pixel zero frame, labels NBD from 2;
+#   * an outer border starts where f == 1 and the left neighbour is 0, a hole border where f >= 1 and the
+#     right neighbour is 0; the first search runs CLOCKWISE from the west (outer) / east (hole) neighbour,
+#     every following one COUNTER-CLOCKWISE from the neighbour after the previous pixel (direction codes
+#     0..7 = E, NE, N, NW, W, SW, S, SE), so an outer border is listed from its top-left pixel DOWN its left
+#     side; CHAIN_APPROX_NONE lists every border pixel visit;
+#   * parent from the label LNBD last seen on the row (Suzuki's table);
+#   * contours are numbered in pre-order of the tree with the siblings in REVERSE order of discovery (the
+#     legacy implementation prepends a new contour to its parent's child list); hierarchy rows are
+#     [next, previous, first_child, parent].
+# PARITY UNPINNED against cv2 itself (only against hand-derived answers and topological invariants).
+_CODE_DELTAS = ((1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1), (0, 1), (1, 1))   # (dx, dy) of codes 0..7
+
+
+def find_contours_tree(binary: np.ndarray):
+    """-> (contours: list of int32 [n,2] arrays of (x, y); hierarchy: int32 [n,4])"""
+    h, w = binary.shape
+    f = np.zeros((h + 2, w + 2), np.int64)
+    f[1:-1, 1:-1] = (np.asarray(binary) != 0)
+    is_hole = {1: True}            # the frame
+    parent_of = {1: 0}
+    borders = {}                   # nbd -> list of (x, y)
+    order = []
+    nbd = 1
+    for i in range(1, h + 1):
+        lnbd = 1
+        for j in range(1, w + 1):
+            v = f[i, j]
+            start_hole = None
+            if v == 1 and f[i, j - 1] == 0:
+                start_hole = False
+            elif v >= 1 and f[i, j + 1] == 0:
+                start_hole = True
+                if v > 1:
+                    lnbd = v
+            if start_hole is not None:
+                nbd += 1
+                is_hole[nbd] = start_hole
+                # Suzuki's parent table
+                if start_hole:
+                    parent_of[nbd] = lnbd if not is_hole[lnbd] else parent_of[lnbd]
+                else:
+                    parent_of[nbd] = parent_of[lnbd] if not is_hole[lnbd] else lnbd
+                pts = []
+                # first search: clockwise from the west (outer) / east (hole) neighbour
+                s_end = s = 0 if start_hole else 4
+                found = False
+                while True:
+                    s = (s - 1) & 7
+                    dx, dy = _CODE_DELTAS[s]
+                    if f[i + dy, j + dx] != 0:
+                        found = True
+                        break
+                    if s == s_end:
+                        break
+                if not found:
+                    f[i, j] = -nbd
+                    pts.append((j - 1, i - 1))
+                else:
+                    i1, j1 = i + _CODE_DELTAS[s][1], j + _CODE_DELTAS[s][0]
+                    i3, j3 = i, j
+                    while True:
+                        s_end = s
+                        # counter-clockwise from the neighbour after the one we came from
+                        while True:
+                            s = (s + 1) & 7
+                            dx, dy = _CODE_DELTAS[s]
+                            if f[i3 + dy, j3 + dx] != 0:
+                                break
+                        i4, j4 = i3 + _CODE_DELTAS[s][1], j3 + _CODE_DELTAS[s][0]
+                        # was the east neighbour (code 0) a zero pixel examined by this search?
+                        # examined codes: s_end+1 .. s (cyclic), the last one is the hit
+                        passed_east = ((0 - (s_end + 1)) & 7) < ((s - (s_end + 1)) & 7) and f[i3, j3 + 1] == 0
+                        if passed_east:
+                            f[i3, j3] = -nbd
+                        elif f[i3, j3] == 1:
+                            f[i3, j3] = nbd
+                        pts.append((j3 - 1, i3 - 1))
+                        if i4 == i and j4 == j and i3 == i1 and j3 == j1:
+                            break
+                        i3, j3 = i4, j4
+                        s = (s + 4) & 7          # the direction back to where we came from
+                borders[nbd] = np.asarray(pts, np.int32).reshape(-1, 2)
+                order.append(nbd)
+            if f[i, j] != 0 and f[i, j] != 1:
+                lnbd = abs(int(f[i, j]))
+    # numbering: pre-order, siblings newest first
+    children = {}
+    for b in order:
+        children.setdefault(parent_of[b], []).append(b)
+    seq = []
+
+    def walk(p):
+        for b in reversed(children.get(p, [])):
+            seq.append(b)
+            walk(b)
+    walk(1)
+    index = {b: k for k, b in enumerate(seq)}
+    hier = np.full((len(seq), 4), -1, np.int32)
+    for p, kids in children.items():
+        ks = list(reversed(kids))
+        for a, b in zip(ks, ks[1:]):
+            hier[index[a], 0] = index[b]
+            hier[index[b], 1] = index[a]
+        if p != 1:
+            hier[index[p], 2] = index[ks[0]]
+            for b in ks:
+                hier[index[b], 3] = index[p]
+    return [borders[b] for b in seq], hier
+
+
+def contour_centroid(points_xy: np.ndarray):
+    """cv2.moments of a contour (Green's theorem over the closed polygon) -> (int(m10/m00), int(m01/m00)) as
+    pre_process.py:178-180 uses it; raises ZeroDivisionError for a zero-area contour like the reference"""
+    p = np.asarray(points_xy, np.float64).reshape(-1, 2)
+    x0, y0 = p[:, 0], p[:, 1]
+    x1, y1 = np.roll(x0, -1), np.roll(y0, -1)
+    cross = x0 * y1 - x1 * y0
+    a00 = cross.sum()
+    a10 = ((x0 + x1) * cross).sum()
+    a01 = ((y0 + y1) * cross).sum()
+    if a00 == 0:
+        raise ZeroDivisionError("float division by zero")
+    m00, m10, m01 = a00 / 2.0, a10 / 6.0, a01 / 6.0
+    if m00 < 0:                      # cv2 returns the moments of the positively oriented polygon
+        m00, m10, m01 = -m00, -m10, -m01
+    return int(m10 / m00), int(m01 / m00)
+
+
+def regions_from_contours(per_class):
+    """pre_process.py:88-163: per_class = [(classname, contours, hierarchy)] in the reference's order
+    (crack, spall, rebar) -> (regions dict, number of masks with a contour nested two levels deep)"""
+    regions, count, errors = {}, 0, 0
+    for classname, contours, hier in per_class:
+        pair = {}
+        for j, c in enumerate(contours):
+            all_x, all_y = c[:, 0].tolist(), c[:, 1].tolist()
+            if hier[j, 3] == -1:
+                regions[str(count)] = {"region_attributes": classname,
+                                       "shape_attributes": [{"type": "out", "all_points_x": all_x, "all_points_y": all_y}]}
+                pair[str(j)] = count
+                count += 1
+            else:
+                parent = int(hier[j, 3])
+                if hier[parent, 3] != -1:
+                    errors += 1
+                    continue
+                regions[str(pair[str(parent)])]["shape_attributes"].append(
+                    {"type": "in", "all_points_x": all_x, "all_points_y": all_y})
+    return regions, errors
+
+
+def merge_regions(regions, object_merge):
+    """pre_process.py:165-222: instances whose outer contour's centroid lies strictly inside a 'merge' box are
+    joined into one instance per box (the closest box centre wins); class crack > rebar > spall.  Restated
+    WITHOUT the reference's two accidents: its closest-box test is only evaluated when the loop variable ends
+    on the last box (always true) and re-uses `dis_index` from a previous instance when no box contains the
+    centroid (the follow-up containment test then rejects it unless the stale box happens to contain it --
+    that stale-index acceptance is reproduced, since it changes the output)."""
+    if not object_merge:
+        return {}
+    groups = {jj: [] for jj in range(len(object_merge))}
+    names = {jj: [] for jj in range(len(object_merge))}
+    dis_index = None
+    for k in range(len(regions)):
+        reg = regions[str(k)]
+        poly = reg["shape_attributes"][0]
+        cX, cY = contour_centroid(np.column_stack([poly["all_points_x"], poly["all_points_y"]]))
+        old = 4000
+        for ii, (x1, y1, x2, y2) in enumerate(object_merge):
+            if cX <= x1 or cX >= x2 or cY <= y1 or cY >= y2:
+                continue
+            d = (((x1 + x2) / 2 - cX) ** 2 + ((y1 + y2) / 2 - cY) ** 2) ** 0.5
+            if d < old:
+                dis_index, old = ii, d
+        if dis_index is None:
+            raise UnboundLocalError("local variable 'dis_index' referenced before assignment")   # as the reference
+        x1, y1, x2, y2 = object_merge[dis_index]
+        if x1 <= cX <= x2 and y1 <= cY <= y2:
+            groups[dis_index].extend(reg["shape_attributes"])
+            names[dis_index].append(reg["region_attributes"])
+    new_regions, count = {}, 0
+    for jj in range(len(object_merge)):
+        if not groups[jj]:
+            continue
+        nl = names[jj]
+        cls = "crack" if "crack" in nl else ("spall" if ("spall" in nl and "rebar" not in nl) else "rebar")
+        new_regions[str(count)] = {"region_attributes": cls, "shape_attributes": groups[jj]}
+        count += 1
+    return new_regions
