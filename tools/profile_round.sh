@@ -1,4 +1,4 @@
-# one gpurun call: bench line + rocprofv3 kernel stats + PMC traffic for the SAME tuned tiles.  usage: bash tools/profile_round.sh r02b <label>
+# one gpurun call: bench line + rocprofv3 kernel stats + PMC traffic for the SAME tuned tiles.  usage: bash tools/profile_round.sh r02c <label>
 TAG=$1; LABEL=${2:-$1}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd /tmp; export TMPDIR=/tmp
