@@ -263,6 +263,8 @@ def main():
     ap.add_argument("--tune-cache", default=None, help="JSON file to load the autotuned tiles from / save them to")
     ap.add_argument("--force-dp", action="store_true",
                     help="initialise RCCL and run the bucketed gradient all-reduce path even with one rank (self-test)")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="data-parallel runs: batch-norm statistics over all ranks (SURVEY.md 8e option; default: per rank)")
     ap.add_argument("--mode", default="auto", choices=("auto", "graph", "program", "eager"),
                     help="how the step is driven: the recorded command list replayed by the native executor "
                          "(default; cut at the all-reduce points when N > 1), its hipGraph capture, or per-launch "
@@ -296,7 +298,7 @@ def main():
     net = YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=args.stage, seed=0, dtype=args.dtype)
     if use_dp:
         from disyolo_amd.dp import enable_data_parallel
-        enable_data_parallel(net)
+        enable_data_parallel(net, sync_bn=args.sync_bn)
     batch = synthetic_batch(B, S, seed=1234 + rank)
     net.set_batch(batch)           # inputs resident in HBM from here on
     if args.dtype == "fp8":
@@ -366,7 +368,7 @@ def main():
                        "images_per_gpu": B, "global_batch": B * world, "image_size": S,
                        "stage": "1: conv1-52 locked (shipped reference source)" if args.stage == 1 else
                                 "2: all 82 layers trainable",
-                       "parallelism": "dp%d" % world, "rccl_buckets": (len(net.dp.buckets) + 1) if net.dp else 0, "optimizer": "adam(tf-form) lr=1e-4", "step_driver": mode,
+                       "parallelism": "dp%d%s" % (world, "+syncbn" if (use_dp and args.sync_bn) else ""), "rccl_buckets": (len(net.dp.buckets) + 1) if net.dp else 0, "optimizer": "adam(tf-form) lr=1e-4", "step_driver": mode,
                        "conv_tiles": "autotuned in-sequence at setup" if args.autotune == "on" else "launcher heuristic",
                        "backbone_pipeline": bool(args.stage == 1 and mode == "program" and args.pipeline == "on"),
                        "final_total_loss": round(loss, 4)},

@@ -229,3 +229,41 @@ def test_empty_and_saturated_detection_edge_cases(dev):
     assert net.det_count.cpu().tolist() == [30, 30]
     d = net.detections.cpu().numpy()
     assert (np.diff(d[:, :, 5], axis=1) <= 0).all() and (d[:, :, 5] > 0.01).all()
+
+
+def test_first_layer_matrix_core_kernel_equals_the_vector_kernel_at_full_size(dev):
+    """Layer 1 at B=2, 576x576: the f32-MFMA kernel (sums the 27 taps in pairs) against the thread-per-pixel
+    kernel (one sequential FMA chain), same f32 image and weights: both are exact-f32 products, the only
+    difference is the summation order of 27 terms, so after the rounding to bf16 they agree bit for bit nearly
+    everywhere and within one bf16 ulp elsewhere."""
+    import os
+    import subprocess
+    import sys
+    g = torch.Generator().manual_seed(9)
+    B, S = 2, 576
+    img = torch.rand(B, S, S, 3, generator=g).to(dev)
+    w = (torch.randn(3, 3, 3, 32, generator=g) * 0.2).to(dev)
+    sc = (torch.rand(32, generator=g) + 0.5).to(dev)
+    sh = (torch.randn(32, generator=g) * 0.1).to(dev)
+    y = torch.empty(B, S, S, 32, dtype=torch.bfloat16, device=dev)
+    L.conv_first_fwd(img, w, sc, sh, y, alpha=0.1)
+    torch.cuda.synchronize()
+    # the vector kernel is selected by an environment variable read once per process: run it in a child
+    path = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out")
+    os.makedirs(path, exist_ok=True)
+    f_in, f_out = os.path.join(path, "first_in.pt"), os.path.join(path, "first_out.pt")
+    torch.save({"img": img.cpu(), "w": w.cpu(), "sc": sc.cpu(), "sh": sh.cpu()}, f_in)
+    code = ("import sys, torch; sys.path.insert(0, %r); import disyolo_amd; from disyolo_amd import lib as L; "
+            "d = torch.load(%r); dev = torch.device('cuda:0'); "
+            "y = torch.empty(%d, %d, %d, 32, dtype=torch.bfloat16, device=dev); "
+            "L.conv_first_fwd(d['img'].to(dev), d['w'].to(dev), d['sc'].to(dev), d['sh'].to(dev), y, alpha=0.1); "
+            "torch.cuda.synchronize(); torch.save(y.cpu(), %r)") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), f_in, B, S, S, f_out)
+    env = dict(os.environ, DISYOLO_FIRST_VALU="1")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=600)
+    want = torch.load(f_out).float()
+    got = y.float().cpu()
+    same = float((got == want).float().mean())
+    assert same > 0.999, same
+    ulp = 2.0 ** -7 * want.abs().clamp_min(2.0 ** -20)
+    assert bool(((got - want).abs() <= ulp).all())
+    os.remove(f_in), os.remove(f_out)
