@@ -95,8 +95,14 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const uint4* x, const f
                                                          const uint4* residual, uint4* y, int64_t nvec, int C,
                                                          float alpha) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // channel of the first element of vector i, carried along instead of a 64-bit modulo per iteration
+  const int chunks = C >> 3;
+  const int cstep = (int)(stride % chunks);
+  int ch = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) % chunks);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-    const int c0 = (int)((i * 8) % C);
+    const int c0 = ch << 3;
+    ch += cstep;
+    if (ch >= chunks) ch -= chunks;
     float v[8];
     unpack8(x[i], v);
     const float4 s0 = *reinterpret_cast<const float4*>(scale + c0), s1 = *reinterpret_cast<const float4*>(scale + c0 + 4);
@@ -273,8 +279,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint4* dy, cons
                                                            const float* shift, const float* cA, const float* cC,
                                                            uint4* dx, int64_t nvec, int C, float alpha) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int chunks = C >> 3;
+  const int cstep = (int)(stride % chunks);
+  int ch = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) % chunks);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-    const int c0 = (int)((i * 8) % C);
+    const int c0 = ch << 3;
+    ch += cstep;
+    if (ch >= chunks) ch -= chunks;
     float g[8], vx[8], sc[8], sh[8], A[8], Cc[8];
     unpack8(dy[i], g);
     unpack8(x[i], vx);
