@@ -498,3 +498,18 @@ def test_autotune_restores_state_and_keeps_results(dev, tmp_path):
         assert np.isfinite(l1) and abs(l0 - l1) <= 0.2 * abs(l0), (l0, l1)
     finally:
         L.TUNED.clear()
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+def test_recorded_training_overfits_one_batch(dev, stage):
+    """End-to-end sanity of the whole step (forward, both losses, backward, optimizer sweeps overlapped with
+    the backward pass, re-pack): 80 recorded steps on ONE synthetic batch make the total loss fall by more
+    than half and stay finite (tools/overfit_check.py: 1971 -> 104 in 300 steps at 192x192, both stages)."""
+    B, S = 2, 96
+    net = YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=stage, seed=0)
+    net.set_batch(O.synthetic_batch(B, S, seed=7))
+    net.shuffle_seed = 11
+    net.build_program()
+    losses = [float(net.train_step(None).cpu()) for _ in range(80)]
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
