@@ -181,3 +181,36 @@ def test_solver_train_loop_cadence_checkpoints_and_schedule(dev, tmp_path):
            max_iter=0, log=lambda s: None)
     assert torch.equal(fresh.params["yolo/convolutional60/weights"], nets[0].params["yolo/convolutional60/weights"])
     assert not torch.equal(fresh.params["yolo/convolutional80/weights"], nets[0].params["yolo/convolutional80/weights"])
+
+
+def test_host_feeder_trains_like_set_batch(dev):
+    """feed.HostFeeder (pinned host batch -> copy stream -> staging -> input buffers, one batch ahead) changes when
+    the inputs arrive, not what is computed: three steps on three different host batches leave the same weights,
+    bit for bit, as set_batch + train_step."""
+    from disyolo_amd.feed import HostFeeder
+    B, S = 2, 64
+    nets = [YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=1, seed=4) for _ in range(2)]
+    for n in nets:
+        seeded_heads(n, 8)
+        n.shuffle_seed = 3
+    batches = [O.synthetic_batch(B, S, seed=300 + t) for t in range(3)]
+    plain, fed = nets
+    for n in nets:
+        n.set_batch(batches[0])
+        n.build_program(det_thresh=0.1)
+    want = []
+    for b in batches:
+        plain.set_batch(b)
+        want.append(float(plain.train_step(None).cpu()))
+    feeder = HostFeeder(fed)
+    feeder.submit(batches[0])
+    got = []
+    for t in range(3):
+        if t + 1 < 3:
+            feeder.submit(batches[t + 1])
+        got.append(float(feeder.step().cpu()))
+    with pytest.raises(RuntimeError):
+        feeder.step()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(got, want)        # (a NaN step -- zero-area positive RoI, SURVEY B14 -- is NaN in both)
+    assert torch.equal(plain.arena, fed.arena) and torch.equal(plain.adam_v, fed.adam_v)
