@@ -456,6 +456,37 @@ extern "C" int disyolo_bn_act_bwd(const void* dy, const void* x, const float* sc
   return DISYOLO_OK;
 }
 
+// bn_act_bwd with the column reduction already done: `partials` f32 [part_rows][C][2] holds (sum g, sum g*xhat)
+// per channel over disjoint row sets (what a data-gradient conv with DISYOLO_CONV_BN_BWD_STATS wrote)
+extern "C" size_t disyolo_bn_act_bwd_partials_workspace(int C) { return C > 0 ? 2 * (size_t)C * sizeof(float) : 0; }
+
+extern "C" int disyolo_bn_act_bwd_partials(const void* dy, const void* x, const float* scale, const float* shift,
+                                           const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                                           int64_t rows, int C, float alpha, const float* partials, int part_rows,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+  DY_REQUIRE(dy && x && scale && shift && mean && rstd && dx && dgamma && dbeta && partials, "bn_act_bwd_partials: null pointer");
+  DY_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && part_rows > 0, "bn_act_bwd_partials: bad shape");
+  if (workspace_bytes < disyolo_bn_act_bwd_partials_workspace(C) || !workspace) {
+    disyolo_set_error("bn_act_bwd_partials: workspace too small");
+    return DISYOLO_E_WORKSPACE;
+  }
+  DY_RECORD_OR_RUN([=](void* s) {
+    return disyolo_bn_act_bwd_partials(dy, x, scale, shift, mean, rstd, dx, dgamma, dbeta, rows, C, alpha, partials, part_rows,
+                                       workspace, workspace_bytes, s);
+  });
+  hipStream_t s = (hipStream_t)stream;
+  float* c1 = (float*)workspace;
+  float* c2 = c1 + C;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_CPB)), dim3(256), 0, s, partials, part_rows, C,
+                     1.0 / (double)rows, scale, mean, rstd, dgamma, dbeta, c1, c2);
+  DY_CHECK_LAUNCH();
+  const int64_t nvec = rows * C / 8;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nvec)), dim3(256), 0, s, (const uint4*)dy, (const uint4*)x,
+                     scale, shift, c1, c2, (uint4*)dx, nvec, C, alpha);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
 // ---- SyncBN building blocks: the phases of bn_finalize / bn_act_bwd as separate calls, so the caller can add
 // the per-channel sums up over the data-parallel ranks between them (f64 [C][2], one all-reduce each) ----
 extern "C" int disyolo_bn_partial_sums(const float* partials, int rows, int C, double* sums, void* stream) {

@@ -28,6 +28,13 @@ struct ConvParams {
   const bf16* residual;
   void* y;
   float* stats;
+  const bf16* bn_x;          // DISYOLO_CONV_BN_BWD_STATS (patch kernel): the target layer's pre-BN conv output ...
+  const float* bn_scale;     // ... its scale / shift / batch mean / rstd ...
+  const float* bn_shift;
+  const float* bn_mean;
+  const float* bn_rstd;
+  float* bn_part;            // ... and the partial sums [tilesM][Cout][2] this launch writes
+  float bn_alpha;
   int B, H, W, C0, C1, Cin;
   int Ho, Wo, Cout;
   int ks, stride, pad_t, pad_l, dmask, dshift;
@@ -598,6 +605,46 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
 // wave holds up to FW of them x NI channel fragments.  LDS per stage: halo [pixels][32 ch] +
 // weights [tap][BN][32], 64-byte rows, 16-byte chunks XOR-swizzled as in the GEMM kernel;
 // 2 stages (compute slice c while slice c+1 lands).
+// batch-norm backward sums of one stored 16-byte chunk (8 channels of one pixel): g = dy*act'(z), xhat
+struct BnBwdLane {
+  float sc[8], sh[8], mu[8], rs[8], s1[8], s2[8];
+  __device__ __forceinline__ void init(const ConvParams& p, int n, bool ok) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      sc[k] = ok ? p.bn_scale[n + k] : 0.f;
+      sh[k] = ok ? p.bn_shift[n + k] : 0.f;
+      mu[k] = ok ? p.bn_mean[n + k] : 0.f;
+      rs[k] = ok ? p.bn_rstd[n + k] : 0.f;
+      s1[k] = s2[k] = 0.f;
+    }
+  }
+  __device__ __forceinline__ void add(const uint4& dy, const uint4& x, float alpha) {
+    float g[8], vx[8];
+    unpack8(dy, g);
+    unpack8(x, vx);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float z = vx[k] * sc[k] + sh[k];
+      const float gg = g[k] * (z > 0.f ? 1.f : alpha);
+      const float xh = (vx[k] - mu[k]) * rs[k];
+      s1[k] += gg;
+      s2[k] += gg * xh;
+    }
+  }
+  // sum over the lanes that hold the same chunk column: lane ids equal modulo CPR8
+  template <int CPR8>
+  __device__ __forceinline__ void reduce() {
+#pragma unroll
+    for (int o = CPR8; o < 64; o <<= 1) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        s1[k] += __shfl_xor(s1[k], o, 64);
+        s2[k] += __shfl_xor(s2[k], o, 64);
+      }
+    }
+  }
+};
+
 template <int NW, int FW, int NI>
 __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH, int PW, int tilesY, int tilesX) {
   constexpr int BN = NI * 16;
@@ -804,6 +851,25 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
       divmod_small(q_of[t] >= 0 ? q_of[t] : 0, PW, py, px);
       m_of[t] = (t < nf_w && q_of[t] >= 0) ? (b * p.Ho + y0 + py) * p.Wo + x0 + px : -1;
     }
+    constexpr int CPR8 = BN / 8;   // 16-byte chunks per pixel row
+    static_assert(64 % CPR8 == 0, "a lane keeps its chunk column over the write-out rounds");
+    constexpr int RPF = (16 * CPR8 + 63) / 64;
+    // batch-norm backward sums (DISYOLO_CONV_BN_BWD_STATS): the target layer's conv output for the chunks this
+    // lane will store, requested now so that the loads fly while the tile is scaled, packed and staged
+    const bool bnb = p.flags & DISYOLO_CONV_BN_BWD_STATS;
+    uint4 bx[FW * RPF];
+    if (bnb) {
+#pragma unroll
+      for (int t = 0; t < FW; ++t)
+#pragma unroll
+        for (int it = 0; it < RPF; ++it) {
+          const int idx = it * 64 + lane;
+          const int m = idx < 16 * CPR8 ? __shfl(m_of[t], idx / CPR8, 64) : -1;
+          const int n = n0 + (idx % CPR8) * 8;
+          bx[t * RPF + it] = (m >= 0 && n < p.Cout) ? *reinterpret_cast<const uint4*>(p.bn_x + (size_t)m * p.Cout + n)
+                                                     : uint4{0, 0, 0, 0};
+        }
+    }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int n = n0 + j * 16 + cq * 4;
@@ -837,19 +903,48 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     bf16* yo = reinterpret_cast<bf16*>(p.y);
-    constexpr int CPR8 = BN / 8;   // 16-byte chunks per pixel row: 2 rounds of 64 lanes per fragment
+    BnBwdLane bl;
+    if (bnb) bl.init(p, n0 + (lane % CPR8) * 8, n0 + (lane % CPR8) * 8 < p.Cout);
 #pragma unroll
     for (int t = 0; t < FW; ++t) {
 #pragma unroll
-      for (int it = 0; it < 16 * CPR8 / 64; ++it) {
+      for (int it = 0; it < RPF; ++it) {
         const int idx = it * 64 + lane;
         const int r16 = idx / CPR8, ch = idx % CPR8;
         // the pixel of row r16 of this fragment lives in lane r16 (any cq) of m_of[t]
         const int m = __shfl(m_of[t], r16, 64);
         const int n = n0 + ch * 8;
-        if (m >= 0 && n < p.Cout)
-          *reinterpret_cast<uint4*>(yo + (size_t)m * p.Cout + n) =
-              *reinterpret_cast<const uint4*>(sw + (t * 16 + r16) * ROWP + ch * 16);
+        if (m >= 0 && n < p.Cout) {
+          const uint4 o = *reinterpret_cast<const uint4*>(sw + (t * 16 + r16) * ROWP + ch * 16);
+          *reinterpret_cast<uint4*>(yo + (size_t)m * p.Cout + n) = o;
+          if (bnb) bl.add(o, bx[t * RPF + it], p.bn_alpha);
+        }
+      }
+    }
+    if (bnb) {
+      // lanes -> waves (fixed order through LDS) -> one row of partials per patch
+      bl.template reduce<CPR8>();
+      float* red = reinterpret_cast<float*>(smem);  // [NW][BN][2]; the tiles are dead by now
+      if (lane < CPR8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          red[(wave * BN + lane * 8 + k) * 2 + 0] = bl.s1[k];
+          red[(wave * BN + lane * 8 + k) * 2 + 1] = bl.s2[k];
+        }
+      }
+      __syncthreads();
+      for (int nl = tid; nl < BN; nl += NW * 64) {
+        const int n = n0 + nl;
+        if (n < p.Cout) {
+          float s = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int w_ = 0; w_ < NW; ++w_) {
+            s += red[(w_ * BN + nl) * 2 + 0];
+            s2 += red[(w_ * BN + nl) * 2 + 1];
+          }
+          p.bn_part[((size_t)mt * p.Cout + n) * 2 + 0] = s;
+          p.bn_part[((size_t)mt * p.Cout + n) * 2 + 1] = s2;
+        }
       }
     }
     return;
@@ -1124,6 +1219,12 @@ int validate(const disyolo_conv_desc* d) {
 
 extern "C" size_t disyolo_conv_desc_size(void) { return sizeof(disyolo_conv_desc); }
 
+extern "C" int disyolo_conv2d_bn_bwd_stats_ok(const disyolo_conv_desc* d) {
+  if (!d || (d->flags & DISYOLO_CONV_OUT_F32) || d->Cout % 8) return 0;
+  const int sel = pick_tile(d, d->B * d->Ho * d->Wo);
+  return (sel & 0xff) >= 16 && halo_ok(d, sel & 0xff, nullptr) ? 1 : 0;
+}
+
 extern "C" int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d) {
   if (!d) return DISYOLO_E_ARG;
   const int M = d->B * d->Ho * d->Wo;
@@ -1191,6 +1292,15 @@ extern "C" int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream) {
   p.residual = (const bf16*)d->residual;
   p.y = d->y;
   p.stats = d->stats;
+  p.bn_x = nullptr; p.bn_scale = p.bn_shift = p.bn_mean = p.bn_rstd = nullptr; p.bn_part = nullptr; p.bn_alpha = 0.f;
+  if (d->flags & DISYOLO_CONV_BN_BWD_STATS) {
+    DY_REQUIRE(d->bn_x && d->bn_scale && d->bn_shift && d->bn_mean && d->bn_rstd && d->bn_partials,
+               "conv: BN_BWD_STATS flag with a null bn_* pointer");
+    DY_REQUIRE(disyolo_conv2d_bn_bwd_stats_ok(d) == 1,
+               "conv: BN_BWD_STATS needs the patch kernel (tile 16-18 on a shape it covers), bf16 output, Cout %% 8 == 0");
+    p.bn_x = (const bf16*)d->bn_x; p.bn_scale = d->bn_scale; p.bn_shift = d->bn_shift; p.bn_mean = d->bn_mean;
+    p.bn_rstd = d->bn_rstd; p.bn_part = d->bn_partials; p.bn_alpha = d->bn_alpha;
+  }
   p.B = d->B; p.H = d->H; p.W = d->W; p.C0 = d->C0; p.C1 = d->C1; p.Cin = d->C0 + d->C1;
   p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
   p.ks = d->ksize; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("DISYOLO_LIB", os.path.join(_HERE, "libdisyolo_hip.so"
 GRAD_LD = 32
 ROI_MAX = 16
 ROI_W = 12
-CONV_LEAKY, CONV_OUT_F32, CONV_STATS = 1, 2, 4
+CONV_LEAKY, CONV_OUT_F32, CONV_STATS, CONV_BN_BWD_STATS = 1, 2, 4, 8
 
 
 class DisyoloError(RuntimeError):
@@ -38,6 +38,8 @@ class ConvDesc(C.Structure):
         ("x0", C.c_void_p), ("x1", C.c_void_p), ("w", C.c_void_p),
         ("scale", C.c_void_p), ("shift", C.c_void_p), ("residual", C.c_void_p),
         ("y", C.c_void_p), ("stats", C.c_void_p),
+        ("bn_x", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("bn_mean", C.c_void_p),
+        ("bn_rstd", C.c_void_p), ("bn_partials", C.c_void_p), ("bn_alpha", C.c_float),
     ]
 
 
@@ -48,6 +50,7 @@ _SIGS = {
     "disyolo_find_contours": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
                                         C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "disyolo_conv2d_stats_rows": (C.c_int, [C.POINTER(ConvDesc)]),
+    "disyolo_conv2d_bn_bwd_stats_ok": (C.c_int, [C.POINTER(ConvDesc)]),
     "disyolo_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "disyolo_conv2d_tile": (C.c_int, [C.POINTER(ConvDesc)] + [C.POINTER(C.c_int)] * 4),
     "disyolo_conv_first_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
@@ -76,6 +79,9 @@ _SIGS = {
     "disyolo_bn_fold": (C.c_int, [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 2 + [C.c_int, C.c_void_p]),
     "disyolo_bn_act_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_float, C.c_void_p]),
     "disyolo_bn_act_bwd_workspace": (C.c_size_t, [C.c_int64, C.c_int]),
+    "disyolo_bn_act_bwd_partials_workspace": (C.c_size_t, [C.c_int]),
+    "disyolo_bn_act_bwd_partials": (C.c_int, [C.c_void_p] * 9 + [C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_int,
+                                              C.c_void_p, C.c_size_t, C.c_void_p]),
     "disyolo_bn_partial_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "disyolo_bn_finalize_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int64] + [C.c_void_p] * 4 + [C.c_float, C.c_float] +
                                  [C.c_void_p] * 5),
@@ -253,7 +259,11 @@ def same_pads(size: int, k: int, s: int):
 
 
 def make_conv_desc(x0, w_packed, y, ksize, stride, *, x1=None, scale=None, shift=None, residual=None, stats=None,
-                   leaky=False, out_f32=False, alpha=0.1, tile=0, in_div=1, pads=None, out_hw=None) -> ConvDesc:
+                   leaky=False, out_f32=False, alpha=0.1, tile=0, in_div=1, pads=None, out_hw=None,
+                   bn_bwd=None) -> ConvDesc:
+    """``bn_bwd`` = (x, scale, shift, mean, rstd, partials, alpha) of the batch-normalised layer whose output
+    gradient ``y`` becomes final with this conv: its batch-norm backward sums are emitted by the epilogue (only the
+    3x3 patch kernel can: check ``conv2d_bn_bwd_stats_ok`` on the descriptor without it first)"""
     B, H, W, C0 = x0.shape
     C1 = 0 if x1 is None else x1.shape[3]
     if out_hw is None:
@@ -275,9 +285,18 @@ def make_conv_desc(x0, w_packed, y, ksize, stride, *, x1=None, scale=None, shift
     d.x0, d.x1, d.w = _p(x0), _p(x1), _p(w_packed)
     d.scale, d.shift, d.residual = _p(scale), _p(shift), _p(residual)
     d.y, d.stats = _p(y), _p(stats)
+    if bn_bwd is not None:
+        d.flags |= CONV_BN_BWD_STATS
+        d.bn_x, d.bn_scale, d.bn_shift, d.bn_mean, d.bn_rstd, d.bn_partials = (_p(t) for t in bn_bwd[:6])
+        d.bn_alpha = bn_bwd[6]
     # the struct only holds raw pointers: keep the tensors alive as long as the descriptor
-    d._keepalive = (x0, x1, w_packed, scale, shift, residual, y, stats)
+    d._keepalive = (x0, x1, w_packed, scale, shift, residual, y, stats, bn_bwd)
     return d
+
+
+def conv2d_bn_bwd_stats_ok(d: ConvDesc) -> bool:
+    """does this descriptor run a kernel that can emit the batch-norm backward sums (make_conv_desc(bn_bwd=...))?"""
+    return load().disyolo_conv2d_bn_bwd_stats_ok(C.byref(d)) == 1
 
 
 def conv2d_stats_rows(d: ConvDesc) -> int:
@@ -555,6 +574,18 @@ def colstats_rows(rows, C_) -> int:
 
 def colstats(x, stats, rows, C_) -> None:
     _check(load().disyolo_colstats(_p(x), _p(stats), rows, C_, _stream()), "colstats")
+
+
+def bn_act_bwd_partials(dy, x, scale, shift, mean, rstd, dx, dgamma, dbeta, rows, C_, partials, part_rows,
+                        ws: Workspace, alpha=0.1) -> None:
+    """bn_act_bwd whose column reduction was done by the conv that produced dy (make_conv_desc(bn_bwd=...))"""
+    _need(partials, torch.float32, "partials")
+    if partials.numel() < part_rows * C_ * 2:
+        raise DisyoloError("bn_act_bwd_partials: partials smaller than part_rows x C x 2")
+    buf = ws.get(load().disyolo_bn_act_bwd_partials_workspace(C_))
+    _check(load().disyolo_bn_act_bwd_partials(_p(dy), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(dx), _p(dgamma),
+                                              _p(dbeta), rows, C_, alpha, _p(partials), part_rows, _p(buf), buf.numel(),
+                                              _stream()), "bn_act_bwd_partials")
 
 
 def bn_partial_sums(partials, rows, C_, sums) -> None:

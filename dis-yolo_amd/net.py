@@ -35,7 +35,7 @@ class Layer:
                  "Wo", "w", "bias", "gamma", "beta", "mm", "mv", "scale", "shift", "mean", "rstd", "wp", "wdg", "raw",
                  "act", "stats", "stats_rows", "desc", "grad", "grad_set", "need_grad", "dw", "dbias", "dgamma",
                  "dbeta", "dx", "pad_t", "pad_l", "dgrad_descs", "wgrad_desc", "cout_pad",
-                 "act8", "w8", "s_w", "s_out", "escale", "desc8", "dual16", "bn_sums", "bwd_local", "bwd_global")
+                 "act8", "w8", "s_w", "s_out", "escale", "desc8", "dual16", "bn_sums", "bwd_local", "bwd_global", "bwd_part", "bwd_part_rows")
 
     def __init__(self, idx, cin, cout, k, stride, kind, src, src_up=None, shortcut=None):
         self.idx, self.cin, self.cout, self.k, self.stride, self.kind = idx, cin, cout, k, stride, kind
@@ -814,13 +814,39 @@ class YOLONet(object):
                     [h.dx for h in heads], self.losses, self.ws)
         self._mask_loss_pending = side
 
-    def _accumulate_into(self, tgt: Layer, desc_kw: dict, dx: torch.Tensor, cin_eff: int, k: int, in_div: int) -> None:
-        """one data-gradient conv writing (first contribution) or accumulating into tgt.grad"""
+    def _accumulate_into(self, tgt: Layer, desc_kw: dict, dx: torch.Tensor, cin_eff: int, k: int, in_div: int,
+                         final: bool = False) -> None:
+        """one data-gradient conv writing (first contribution) or accumulating into tgt.grad.  ``final``: this is
+        the last contribution to tgt.grad and tgt is batch-normalised -- if the conv runs the 3x3 patch kernel, its
+        epilogue also emits tgt's batch-norm backward sums (bn_act_bwd then skips its column reduction)"""
         out = desc_kw.get("tmp", tgt.grad)
         first = not tgt.grad_set
+        res = None if (first or "tmp" in desc_kw) else tgt.grad
         d = L.make_conv_desc(dx, desc_kw["w"], out, k, 1, in_div=in_div, pads=desc_kw["pads"], out_hw=desc_kw["out_hw"],
-                             residual=None if (first or "tmp" in desc_kw) else tgt.grad)
+                             residual=res)
+        if final and L.TUNER is None and L.conv2d_bn_bwd_stats_ok(d):     # (the tuner swaps tiles under the descriptor)
+            rows = L.conv2d_stats_rows(d)
+            need = rows * tgt.cout * 2
+            if tgt.bwd_part is None or tgt.bwd_part.numel() < need:
+                tgt.bwd_part = torch.empty(need, dtype=torch.float32, device=self.device)
+            tgt.bwd_part_rows = rows
+            d = L.make_conv_desc(dx, desc_kw["w"], out, k, 1, in_div=in_div, pads=desc_kw["pads"], out_hw=desc_kw["out_hw"],
+                                 residual=res,
+                                 bn_bwd=(tgt.raw, tgt.scale, tgt.shift, tgt.mean, tgt.rstd, tgt.bwd_part, cfg.ALPHA))
         L.conv2d_fwd(d)
+
+    def _final_writers(self, visit) -> Dict[int, Tuple[int, str]]:
+        """layer idx -> (idx of the layer whose backward makes its output gradient final, how: "direct" = a
+        data-gradient conv straight into it, "up" = through the 2x upsampling, "add" = a shortcut's add)"""
+        last: Dict[int, Tuple[int, str]] = {}
+        for l in visit:
+            if l.lock:
+                continue
+            if l.kind != "lin" and l.shortcut is not None and self.by_idx[l.shortcut].grad is not None:
+                last[l.shortcut] = (l.idx, "add")
+            for mode, tgt, _ in l.dgrad_descs:
+                last[tgt.idx] = (l.idx, mode)
+        return last
 
     def backward_order(self) -> List[Layer]:
         """the order backward() visits the layers in: the three detection heads (75,74 / 67,66 / 59,58)
@@ -843,6 +869,10 @@ class YOLONet(object):
         # lane still runs the detection filter and the mask loss; the mask subnet follows.
         visit = self.backward_order()
         order = [l for l in visit if not l.lock]
+        fuse_bn = os.environ.get("DISYOLO_BN_FUSE", "1") != "0" and not self.sync_bn
+        final_of = self._final_writers(visit) if fuse_bn else {}
+        for l in self.layers:
+            l.bwd_part_rows = 0
         # (data parallelism: the sweep must follow the bucket's all-reduce -- it stays in optimizer_step)
         overlap_opt = sweep and self.dp is None and self.n_params > 0 and os.environ.get("DISYOLO_OPT_OVERLAP", "1") != "0"
         if overlap_opt:
@@ -873,6 +903,10 @@ class YOLONet(object):
                     self._sync_sums(l.bwd_global)
                     L.bn_bwd_apply_sums(l.grad, l.raw, l.scale, l.shift, l.mean, l.rstd, l.bwd_local, l.bwd_global,
                                         M * self.dp.world_size, l.dx, l.dgamma, l.dbeta, M, l.cout, self.ws, cfg.ALPHA)
+                elif l.bwd_part_rows:
+                    # the patch conv that made l.grad final left the batch-norm backward sums, one row per patch
+                    L.bn_act_bwd_partials(l.grad, l.raw, l.scale, l.shift, l.mean, l.rstd, l.dx, l.dgamma, l.dbeta, M,
+                                          l.cout, l.bwd_part, l.bwd_part_rows, self.ws, cfg.ALPHA)
                 else:
                     L.bn_act_bwd(l.grad, l.raw, l.scale, l.shift, l.mean, l.rstd, l.dx, l.dgamma, l.dbeta, M, l.cout,
                                  self.ws, cfg.ALPHA)
@@ -915,7 +949,9 @@ class YOLONet(object):
 
             for mode, tgt, kw in l.dgrad_descs:
                 if mode == "direct":
-                    self._accumulate_into(tgt, kw, dx, l.cin, l.k, l.stride)
+                    final = (final_of.get(tgt.idx) == (l.idx, "direct") and not tgt.lock and tgt.kind != "lin"
+                             and tgt.cout % 8 == 0 and tgt.raw is not None)
+                    self._accumulate_into(tgt, kw, dx, l.cin, l.k, l.stride, final)
                     tgt.grad_set = True
                 else:
                     self._accumulate_into(tgt, kw, dx, l.cin, l.k, l.stride)

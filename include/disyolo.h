@@ -46,8 +46,18 @@ const char* disyolo_last_error(void);
 enum {
   DISYOLO_CONV_LEAKY = 1,       /* y = max(alpha*y, y) after scale/shift            */
   DISYOLO_CONV_OUT_F32 = 2,     /* y is f32 (head logits / score maps), else bf16    */
-  DISYOLO_CONV_STATS = 4        /* also emit per-channel (sum, sum of squares) of the
+  DISYOLO_CONV_STATS = 4,       /* also emit per-channel (sum, sum of squares) of the
                                    raw accumulators into `stats` (training BN, :90)  */
+  DISYOLO_CONV_BN_BWD_STATS = 8 /* y is the (now final) gradient wrt the OUTPUT of a batch-
+                                   normalised layer: also emit that layer's batch-norm
+                                   backward sums, per channel over this block's pixels,
+                                   (sum g, sum g*xhat) with g = y*act'(bn_x*bn_scale+bn_shift),
+                                   xhat = (bn_x-bn_mean)*bn_rstd, from the bf16 values
+                                   stored to y, into `bn_partials` -- the column reduction
+                                   disyolo_bn_act_bwd would otherwise start with.  Only the
+                                   3x3 patch kernel has this epilogue (tile ids 16-18:
+                                   disyolo_conv2d_bn_bwd_stats_ok tells), bf16 y,
+                                   Cout % 8 == 0 (TF autodiff of :68-107)                */
 };
 
 typedef struct disyolo_conv_desc {
@@ -78,6 +88,14 @@ typedef struct disyolo_conv_desc {
   const void* residual;   /* bf16 [B,Ho,Wo,Cout] added after the activation, or NULL  */
   void* y;                /* bf16 or f32 [B,Ho,Wo,Cout]                               */
   float* stats;           /* f32 [disyolo_conv2d_stats_rows][Cout][2] or NULL         */
+  /* DISYOLO_CONV_BN_BWD_STATS only (else ignored): */
+  const void* bn_x;       /* bf16 [B,Ho,Wo,Cout]: the conv output the target layer normalised */
+  const float* bn_scale;  /* [Cout] gamma*rstd                                         */
+  const float* bn_shift;  /* [Cout] beta - mean*gamma*rstd                             */
+  const float* bn_mean;   /* [Cout] batch mean                                         */
+  const float* bn_rstd;   /* [Cout] 1/sqrt(var+eps)                                    */
+  float* bn_partials;     /* f32 [disyolo_conv2d_stats_rows][Cout][2]                  */
+  float bn_alpha;         /* the target layer's leaky slope                            */
 } disyolo_conv_desc;
 
 /* Host-side (no device work): the contour extraction of the dataset pre-processing, cv2.findContours(img,
@@ -91,6 +109,8 @@ int disyolo_find_contours(const uint8_t* binary, int h, int w, int32_t* points_x
                           int64_t* n_points);
 /* sizeof(disyolo_conv_desc) as this library was built: a binding checks its mirror against it */
 size_t disyolo_conv_desc_size(void);
+/* 1 when a call with this descriptor runs a kernel that can emit DISYOLO_CONV_BN_BWD_STATS (the patch kernel) */
+int disyolo_conv2d_bn_bwd_stats_ok(const disyolo_conv_desc* d);
 /* rows of the `stats` partial buffer a call with this descriptor writes */
 int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d);
 int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream);
@@ -215,6 +235,14 @@ int disyolo_bn_act_bwd(const void* dy, const void* x, const float* scale, const 
                        const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                        int64_t rows, int C, float alpha, void* workspace, size_t workspace_bytes,
                        void* stream);
+/* the same when the per-channel sums (sum g, sum g*xhat) over disjoint row sets are already in
+ * `partials` f32 [part_rows][C][2]: written by the data-gradient conv that produced dy, with
+ * DISYOLO_CONV_BN_BWD_STATS (part_rows = disyolo_conv2d_stats_rows of that conv). */
+size_t disyolo_bn_act_bwd_partials_workspace(int C);
+int disyolo_bn_act_bwd_partials(const void* dy, const void* x, const float* scale, const float* shift,
+                                const float* mean, const float* rstd, void* dx, float* dgamma,
+                                float* dbeta, int64_t rows, int C, float alpha, const float* partials,
+                                int part_rows, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- small data-movement ops of the backward pass ---- */
 /* dst[b,y,x,c] = sum of the 2x2 block of src (gradient of resize_nearest_neighbor x2),

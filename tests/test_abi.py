@@ -36,8 +36,8 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_table_matches_header():
     assert sorted(L.EXPORTS) == declared_functions()
     assert L.load().disyolo_version() >= 100
-    # 16 x int32/float + 8 pointers, no padding; the library reports the size it was built with
-    assert ctypes.sizeof(L.ConvDesc) == L.load().disyolo_conv_desc_size() == 128
+    # 16 x int32/float + 8 pointers, + 6 pointers and a float (padded) of the batch-norm backward epilogue
+    assert ctypes.sizeof(L.ConvDesc) == L.load().disyolo_conv_desc_size() == 184
 
 
 def test_argument_errors_are_reported_not_thrown():

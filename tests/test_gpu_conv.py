@@ -328,3 +328,96 @@ def test_wgrad_fused_concat(dev):
     L.conv2d_wgrad(d, dy.to(torch.bfloat16).to(dev), 32, dw, L.Workspace(dev))
     torch.cuda.synchronize()
     check(dw, w.grad, 1e-4, 2e-4 * float(w.grad.abs().max()))
+
+
+BN_BWD_CASES = [
+    # B, H, W, Cin, Cout, tile, residual
+    (2, 18, 18, 64, 128, 16, True),        # patch kernel, 8 waves
+    (2, 18, 36, 64, 72, 17, False),        # 4 waves, ragged channel tile (72 = 64 + 8)
+    (2, 18, 18, 96, 64, 18, True),         # 32 channels per block: one write-out round
+    (3, 9, 9, 256, 256, 16, False),        # 9x9 patch = whole image, 6 of 24 fragment slots used
+    (1, 36, 36, 64, 64, 16, True),         # four patches per image
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,tile,with_res", BN_BWD_CASES)
+def test_patch_conv_emits_batchnorm_backward_sums(dev, B, H, W, Cin, Cout, tile, with_res):
+    """DISYOLO_CONV_BN_BWD_STATS: a patch-kernel conv whose output is the final gradient wrt a batch-normalised
+    layer's output also writes, per patch, that layer's (sum g, sum g*xhat) -- computed from the bf16 values it
+    stores, so summed over the patches they equal the column reduction over the stored tensor (f32 sums: 1e-4 of
+    the column's sum of magnitudes).  The output itself is unchanged by the flag, bit for bit."""
+    g = torch.Generator().manual_seed(B + H + Cin + Cout + tile)
+    x = bf16r(torch.randn(B, H, W, Cin, generator=g))
+    w = bf16r(torch.randn(3, 3, Cin, Cout, generator=g) / (9 * Cin) ** 0.5)
+    res = bf16r(torch.randn(B, H, W, Cout, generator=g)) if with_res else None
+    bn_x = bf16r(torch.randn(B, H, W, Cout, generator=g) * 2 + 0.3)
+    mean = torch.randn(Cout, generator=g) * 0.2 + 0.3
+    rstd = torch.rand(Cout, generator=g) + 0.3
+    scale = torch.randn(Cout, generator=g) * rstd
+    shift = torch.randn(Cout, generator=g) * 0.5 - mean * scale
+    xd, wd = x.to(torch.bfloat16).to(dev), pack_ref(w).to(torch.bfloat16).to(dev)
+    resd = res.to(torch.bfloat16).to(dev) if with_res else None
+    y0 = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=dev)
+    y1 = torch.empty_like(y0)
+    plain = L.make_conv_desc(xd, wd, y0, 3, 1, residual=resd, tile=tile)
+    assert L.conv2d_bn_bwd_stats_ok(plain)
+    assert not L.conv2d_bn_bwd_stats_ok(L.make_conv_desc(xd, wd, y0, 3, 1, residual=resd, tile=3))      # a GEMM tile cannot
+    L.conv2d_fwd(plain)
+    rows = L.conv2d_stats_rows(plain)
+    part = torch.full((rows, Cout, 2), float("nan"), device=dev)
+    dev_t = [t.to(dev) for t in (scale, shift, mean, rstd)]
+    L.conv2d_fwd(L.make_conv_desc(xd, wd, y1, 3, 1, residual=resd, tile=tile,
+                                  bn_bwd=(bn_x.to(torch.bfloat16).to(dev), dev_t[0], dev_t[1], dev_t[2], dev_t[3], part, 0.1)))
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    assert torch.isfinite(part).all(), "a partial-sum row was not written"
+    dy = y1.double().cpu().reshape(-1, Cout)
+    vx = bn_x.reshape(-1, Cout)
+    z = vx * scale.double() + shift.double()
+    gg = dy * torch.where(z > 0, 1.0, 0.1)
+    xh = (vx - mean.double()) * rstd.double()
+    got = part.double().sum(0).cpu()
+    for q, term in ((0, gg), (1, gg * xh)):
+        want = term.sum(0)
+        tol = 1e-4 * term.abs().sum(0) + 1e-6
+        assert ((got[:, q] - want).abs() <= tol).all(), (q, float((got[:, q] - want).abs().max()))
+    with pytest.raises(L.DisyoloError):       # the flag on a kernel without that epilogue is refused, not ignored
+        L.conv2d_fwd(L.make_conv_desc(xd, wd, y1, 3, 1, residual=resd, tile=3,
+                                      bn_bwd=(bn_x.to(torch.bfloat16).to(dev), dev_t[0], dev_t[1], dev_t[2], dev_t[3], part, 0.1)))
+
+
+def test_bn_act_bwd_from_conv_partials_matches_the_plain_path(dev):
+    """bn_act_bwd_partials(partials of the patch conv) == bn_act_bwd(column reduction over dy, x) up to the f32
+    summation order of the two reductions (dgamma / dbeta to 2e-5 of the sum of magnitudes; dx within one bf16 ulp)."""
+    B, H, W, Cin, Cout = 4, 18, 18, 128, 256
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(Cout, 9 * Cin, generator=g) / (9 * Cin) ** 0.5).to(torch.bfloat16).to(dev)
+    raw = (torch.randn(B, H, W, Cout, generator=g) * 1.5).to(torch.bfloat16).to(dev)
+    mean = raw.float().reshape(-1, Cout).mean(0)
+    rstd = 1.0 / torch.sqrt(raw.float().reshape(-1, Cout).var(0, unbiased=False) + 1e-5)
+    scale = torch.randn(Cout, generator=g).to(dev) * rstd
+    shift = (torch.randn(Cout, generator=g) * 0.3).to(dev) - mean * scale
+    M = B * H * W
+    ws = L.Workspace(dev)
+    outs = []
+    for fused in (False, True):
+        dy = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=dev)
+        dx = torch.empty_like(dy)
+        dgamma, dbeta = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev)
+        if fused:
+            probe = L.make_conv_desc(x, w, dy, 3, 1, tile=16)
+            rows = L.conv2d_stats_rows(probe)
+            part = torch.empty(rows, Cout, 2, device=dev)
+            L.conv2d_fwd(L.make_conv_desc(x, w, dy, 3, 1, tile=16, bn_bwd=(raw, scale, shift, mean, rstd, part, 0.1)))
+            L.bn_act_bwd_partials(dy, raw, scale, shift, mean, rstd, dx, dgamma, dbeta, M, Cout, part, rows, ws, 0.1)
+        else:
+            L.conv2d_fwd(L.make_conv_desc(x, w, dy, 3, 1, tile=16))
+            L.bn_act_bwd(dy, raw, scale, shift, mean, rstd, dx, dgamma, dbeta, M, Cout, ws, 0.1)
+        torch.cuda.synchronize()
+        outs.append((dx.float().cpu(), dgamma.cpu(), dbeta.cpu(), dy.float().cpu()))
+    assert torch.equal(outs[0][3], outs[1][3])
+    mag = outs[0][3].abs().reshape(-1, Cout).sum(0)
+    assert ((outs[0][2] - outs[1][2]).abs() <= 2e-5 * mag + 1e-6).all()
+    assert ((outs[0][1] - outs[1][1]).abs() <= 2e-5 * mag * 4 + 1e-6).all()
+    check(outs[1][0], outs[0][0], 2.0 ** -7, 1e-4)
