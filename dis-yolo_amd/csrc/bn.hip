@@ -277,7 +277,8 @@ __device__ __forceinline__ void load8(const float* p, float* o) {
 }
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint4* dy, const uint4* x, const float* scale,
                                                            const float* shift, const float* cA, const float* cC,
-                                                           uint4* dx, int64_t nvec, int C, float alpha) {
+                                                           uint4* dx, int64_t nvec, int C, float alpha, uint4* sc_grad,
+                                                           int sc_accumulate) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int chunks = C >> 3;
   const int cstep = (int)(stride % chunks);
@@ -287,7 +288,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint4* dy, cons
     ch += cstep;
     if (ch >= chunks) ch -= chunks;
     float g[8], vx[8], sc[8], sh[8], A[8], Cc[8];
-    unpack8(dy[i], g);
+    const uint4 dyv = dy[i];
+    unpack8(dyv, g);
+    if (sc_grad) {
+      // the residual shortcut's gradient (+)= dy (res_conv_bn, yolo/yolo3_net_pos.py:148-151): rides on the read of dy
+      // this pass makes anyway, in place of a separate add kernel; the same arithmetic as disyolo_add_bf16
+      uint4 o = dyv;
+      if (sc_accumulate) {
+        float a[8], b[8];
+        unpack8(dyv, a);
+        unpack8(sc_grad[i], b);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] += b[k];
+        o = pack8(a);
+      }
+      sc_grad[i] = o;
+    }
     unpack8(x[i], vx);
     load8(scale + c0, sc);
     load8(shift + c0, sh);
@@ -422,15 +438,15 @@ extern "C" size_t disyolo_bn_act_bwd_workspace(int64_t rows, int C) {
 
 extern "C" int disyolo_bn_act_bwd(const void* dy, const void* x, const float* scale, const float* shift,
                                   const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
-                                  int64_t rows, int C, float alpha, void* workspace, size_t workspace_bytes,
-                                  void* stream) {
+                                  int64_t rows, int C, float alpha, void* shortcut_grad, int shortcut_accumulate,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
   DY_REQUIRE(dy && x && scale && shift && mean && rstd && dx && dgamma && dbeta, "bn_act_bwd: null pointer");
   DY_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "bn_act_bwd: bad shape");
   if (workspace_bytes < disyolo_bn_act_bwd_workspace(rows, C) || !workspace) {
     disyolo_set_error("bn_act_bwd: workspace too small");
     return DISYOLO_E_WORKSPACE;
   }
-  DY_RECORD_OR_RUN([=](void* s) { return disyolo_bn_act_bwd(dy, x, scale, shift, mean, rstd, dx, dgamma, dbeta, rows, C, alpha, workspace, workspace_bytes, s); });
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_bn_act_bwd(dy, x, scale, shift, mean, rstd, dx, dgamma, dbeta, rows, C, alpha, shortcut_grad, shortcut_accumulate, workspace, workspace_bytes, s); });
   hipStream_t s = (hipStream_t)stream;
   const int nb = colreduce_blocks(rows, C), rpb = colreduce_rpb(rows, C);
   const int chunks = C / 8, cpb = chunks < 256 ? chunks : 256;
@@ -451,7 +467,7 @@ extern "C" int disyolo_bn_act_bwd(const void* dy, const void* x, const float* sc
   const int64_t nvec = rows * C / 8;
   if (!(exp_bn() & 16))
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nvec)), dim3(256), 0, s, (const uint4*)dy, (const uint4*)x,
-                     scale, shift, c1, c2, (uint4*)dx, nvec, C, alpha);
+                     scale, shift, c1, c2, (uint4*)dx, nvec, C, alpha, (uint4*)shortcut_grad, shortcut_accumulate);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }
@@ -463,7 +479,8 @@ extern "C" size_t disyolo_bn_act_bwd_partials_workspace(int C) { return C > 0 ? 
 extern "C" int disyolo_bn_act_bwd_partials(const void* dy, const void* x, const float* scale, const float* shift,
                                            const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                                            int64_t rows, int C, float alpha, const float* partials, int part_rows,
-                                           void* workspace, size_t workspace_bytes, void* stream) {
+                                           void* shortcut_grad, int shortcut_accumulate, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
   DY_REQUIRE(dy && x && scale && shift && mean && rstd && dx && dgamma && dbeta && partials, "bn_act_bwd_partials: null pointer");
   DY_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && part_rows > 0, "bn_act_bwd_partials: bad shape");
   if (workspace_bytes < disyolo_bn_act_bwd_partials_workspace(C) || !workspace) {
@@ -472,7 +489,7 @@ extern "C" int disyolo_bn_act_bwd_partials(const void* dy, const void* x, const 
   }
   DY_RECORD_OR_RUN([=](void* s) {
     return disyolo_bn_act_bwd_partials(dy, x, scale, shift, mean, rstd, dx, dgamma, dbeta, rows, C, alpha, partials, part_rows,
-                                       workspace, workspace_bytes, s);
+                                       shortcut_grad, shortcut_accumulate, workspace, workspace_bytes, s);
   });
   hipStream_t s = (hipStream_t)stream;
   float* c1 = (float*)workspace;
@@ -482,7 +499,7 @@ extern "C" int disyolo_bn_act_bwd_partials(const void* dy, const void* x, const 
   DY_CHECK_LAUNCH();
   const int64_t nvec = rows * C / 8;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nvec)), dim3(256), 0, s, (const uint4*)dy, (const uint4*)x,
-                     scale, shift, c1, c2, (uint4*)dx, nvec, C, alpha);
+                     scale, shift, c1, c2, (uint4*)dx, nvec, C, alpha, (uint4*)shortcut_grad, shortcut_accumulate);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }
@@ -536,7 +553,8 @@ extern "C" int disyolo_bn_bwd_reduce(const void* dy, const void* x, const float*
 // (`count` = rows over all ranks); cA/cC scratch: 2*C floats of workspace
 extern "C" int disyolo_bn_bwd_apply_sums(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
                                          const float* rstd, const double* local_sums, const double* global_sums, int64_t count,
-                                         void* dx, float* dgamma, float* dbeta, int64_t rows, int C, float alpha, void* workspace,
+                                         void* dx, float* dgamma, float* dbeta, int64_t rows, int C, float alpha,
+                                         void* shortcut_grad, int shortcut_accumulate, void* workspace,
                                          size_t workspace_bytes, void* stream) {
   DY_REQUIRE(dy && x && scale && shift && mean && rstd && local_sums && global_sums && dx && dgamma && dbeta,
              "bn_bwd_apply_sums: null pointer");
@@ -547,7 +565,7 @@ extern "C" int disyolo_bn_bwd_apply_sums(const void* dy, const void* x, const fl
   }
   DY_RECORD_OR_RUN([=](void* s) {
     return disyolo_bn_bwd_apply_sums(dy, x, scale, shift, mean, rstd, local_sums, global_sums, count, dx, dgamma, dbeta, rows, C,
-                                     alpha, workspace, workspace_bytes, s);
+                                     alpha, shortcut_grad, shortcut_accumulate, workspace, workspace_bytes, s);
   });
   hipStream_t s = (hipStream_t)stream;
   float* c1 = (float*)workspace;
@@ -557,7 +575,7 @@ extern "C" int disyolo_bn_bwd_apply_sums(const void* dy, const void* x, const fl
   DY_CHECK_LAUNCH();
   const int64_t nvec = rows * C / 8;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nvec)), dim3(256), 0, s, (const uint4*)dy, (const uint4*)x, scale, shift,
-                     c1, c2, (uint4*)dx, nvec, C, alpha);
+                     c1, c2, (uint4*)dx, nvec, C, alpha, (uint4*)shortcut_grad, shortcut_accumulate);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }

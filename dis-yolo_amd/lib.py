@@ -81,7 +81,7 @@ _SIGS = {
     "disyolo_bn_act_bwd_workspace": (C.c_size_t, [C.c_int64, C.c_int]),
     "disyolo_bn_act_bwd_partials_workspace": (C.c_size_t, [C.c_int]),
     "disyolo_bn_act_bwd_partials": (C.c_int, [C.c_void_p] * 9 + [C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_int,
-                                              C.c_void_p, C.c_size_t, C.c_void_p]),
+                                              C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "disyolo_bn_partial_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "disyolo_bn_finalize_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int64] + [C.c_void_p] * 4 + [C.c_float, C.c_float] +
                                  [C.c_void_p] * 5),
@@ -89,8 +89,8 @@ _SIGS = {
     "disyolo_bn_bwd_reduce": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t,
                                         C.c_void_p]),
     "disyolo_bn_bwd_apply_sums": (C.c_int, [C.c_void_p] * 8 + [C.c_int64] + [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_float,
-                                            C.c_void_p, C.c_size_t, C.c_void_p]),
-    "disyolo_bn_act_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t,
+                                            C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "disyolo_bn_act_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
                                                        C.c_void_p]),
     "disyolo_upsample2x_bwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 7 + [C.c_void_p]),
     "disyolo_colsum_workspace": (C.c_size_t, [C.c_int64, C.c_int]),
@@ -577,15 +577,15 @@ def colstats(x, stats, rows, C_) -> None:
 
 
 def bn_act_bwd_partials(dy, x, scale, shift, mean, rstd, dx, dgamma, dbeta, rows, C_, partials, part_rows,
-                        ws: Workspace, alpha=0.1) -> None:
+                        ws: Workspace, alpha=0.1, shortcut_grad=None, shortcut_accumulate=False) -> None:
     """bn_act_bwd whose column reduction was done by the conv that produced dy (make_conv_desc(bn_bwd=...))"""
     _need(partials, torch.float32, "partials")
     if partials.numel() < part_rows * C_ * 2:
         raise DisyoloError("bn_act_bwd_partials: partials smaller than part_rows x C x 2")
     buf = ws.get(load().disyolo_bn_act_bwd_partials_workspace(C_))
     _check(load().disyolo_bn_act_bwd_partials(_p(dy), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(dx), _p(dgamma),
-                                              _p(dbeta), rows, C_, alpha, _p(partials), part_rows, _p(buf), buf.numel(),
-                                              _stream()), "bn_act_bwd_partials")
+                                              _p(dbeta), rows, C_, alpha, _p(partials), part_rows, _p(shortcut_grad),
+                                              int(shortcut_accumulate), _p(buf), buf.numel(), _stream()), "bn_act_bwd_partials")
 
 
 def bn_partial_sums(partials, rows, C_, sums) -> None:
@@ -608,11 +608,12 @@ def bn_bwd_reduce(dy, x, scale, shift, mean, rstd, rows, C_, sums, ws: Workspace
 
 
 def bn_bwd_apply_sums(dy, x, scale, shift, mean, rstd, local_sums, global_sums, count, dx, dgamma, dbeta, rows, C_,
-                      ws: Workspace, alpha=0.1) -> None:
+                      ws: Workspace, alpha=0.1, shortcut_grad=None, shortcut_accumulate=False) -> None:
     buf = ws.get(2 * C_ * 4)
     _check(load().disyolo_bn_bwd_apply_sums(_p(dy), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(local_sums),
-                                            _p(global_sums), count, _p(dx), _p(dgamma), _p(dbeta), rows, C_, alpha, _p(buf),
-                                            buf.numel(), _stream()), "bn_bwd_apply_sums")
+                                            _p(global_sums), count, _p(dx), _p(dgamma), _p(dbeta), rows, C_, alpha,
+                                            _p(shortcut_grad), int(shortcut_accumulate), _p(buf), buf.numel(), _stream()),
+           "bn_bwd_apply_sums")
 
 
 def bn_fold(gamma, beta, mm, mv, eps, scale, shift) -> None:
@@ -625,11 +626,14 @@ def bn_act_fwd(x, scale, shift, residual, y, rows, C_, alpha=0.1) -> None:
            "bn_act_fwd")
 
 
-def bn_act_bwd(dy, x, scale, shift, mean, rstd, dx, dgamma, dbeta, rows, C_, ws: Workspace, alpha=0.1) -> None:
+def bn_act_bwd(dy, x, scale, shift, mean, rstd, dx, dgamma, dbeta, rows, C_, ws: Workspace, alpha=0.1,
+               shortcut_grad=None, shortcut_accumulate=False) -> None:
+    """``shortcut_grad``: the residual shortcut's gradient buffer receives dy (or dy + itself) in the same pass"""
     need = load().disyolo_bn_act_bwd_workspace(rows, C_)
     buf = ws.get(need)
     _check(load().disyolo_bn_act_bwd(_p(dy), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(dx), _p(dgamma),
-                                     _p(dbeta), rows, C_, alpha, _p(buf), buf.numel(), _stream()), "bn_act_bwd")
+                                     _p(dbeta), rows, C_, alpha, _p(shortcut_grad), int(shortcut_accumulate), _p(buf),
+                                     buf.numel(), _stream()), "bn_act_bwd")
 
 
 def mask_paste(masks, rects, classids, image_h: int, image_w: int, full_masks, merged) -> None:

@@ -895,6 +895,13 @@ class YOLONet(object):
             else:
                 if not l.grad_set:
                     raise L.DisyoloError("layer %d received no gradient" % l.idx)
+                # a residual layer hands its output gradient on to the shortcut's source (res_conv_bn, :148-151): that
+                # copy / add rides on the batch-norm backward's apply pass, which reads l.grad anyway
+                sc = self.by_idx[l.shortcut] if l.shortcut is not None else None
+                if sc is not None and sc.grad is None:
+                    sc = None
+                fuse_sc = sc is not None and os.environ.get("DISYOLO_SHORTCUT_FUSE", "1") != "0"
+                kw = dict(shortcut_grad=sc.grad, shortcut_accumulate=sc.grad_set) if fuse_sc else {}
                 if self.sync_bn:
                     # (sum g, sum g*xhat) of this rank -> the same over all ranks -> dx; dgamma / dbeta stay local
                     L.bn_bwd_reduce(l.grad, l.raw, l.scale, l.shift, l.mean, l.rstd, M, l.cout, l.bwd_local, self.ws, cfg.ALPHA)
@@ -902,20 +909,19 @@ class YOLONet(object):
                                  4 * l.cout, 4 * l.cout)
                     self._sync_sums(l.bwd_global)
                     L.bn_bwd_apply_sums(l.grad, l.raw, l.scale, l.shift, l.mean, l.rstd, l.bwd_local, l.bwd_global,
-                                        M * self.dp.world_size, l.dx, l.dgamma, l.dbeta, M, l.cout, self.ws, cfg.ALPHA)
+                                        M * self.dp.world_size, l.dx, l.dgamma, l.dbeta, M, l.cout, self.ws, cfg.ALPHA, **kw)
                 elif l.bwd_part_rows:
                     # the patch conv that made l.grad final left the batch-norm backward sums, one row per patch
                     L.bn_act_bwd_partials(l.grad, l.raw, l.scale, l.shift, l.mean, l.rstd, l.dx, l.dgamma, l.dbeta, M,
-                                          l.cout, l.bwd_part, l.bwd_part_rows, self.ws, cfg.ALPHA)
+                                          l.cout, l.bwd_part, l.bwd_part_rows, self.ws, cfg.ALPHA, **kw)
                 else:
                     L.bn_act_bwd(l.grad, l.raw, l.scale, l.shift, l.mean, l.rstd, l.dx, l.dgamma, l.dbeta, M, l.cout,
-                                 self.ws, cfg.ALPHA)
+                                 self.ws, cfg.ALPHA, **kw)
                 dx, ld = l.dx, l.cout
-                if l.shortcut is not None:
-                    sc = self.by_idx[l.shortcut]
-                    if sc.grad is not None:
+                if sc is not None:
+                    if not fuse_sc:
                         L.add_bf16(l.grad, sc.grad, accumulate=sc.grad_set)
-                        sc.grad_set = True
+                    sc.grad_set = True
             # the weight gradient is off the critical chain (dx -> dgrad -> next layer's BN
             # backward): in a recorded step it runs on the side lane, overlapping the small
             # latency-bound BN kernels of the following layers

@@ -215,8 +215,8 @@ int disyolo_bn_bwd_reduce(const void* dy, const void* x, const float* scale, con
 int disyolo_bn_bwd_apply_sums(const void* dy, const void* x, const float* scale, const float* shift,
                               const float* mean, const float* rstd, const double* local_sums,
                               const double* global_sums, int64_t count, void* dx, float* dgamma, float* dbeta,
-                              int64_t rows, int C, float alpha, void* workspace, size_t workspace_bytes,
-                              void* stream);
+                              int64_t rows, int C, float alpha, void* shortcut_grad, int shortcut_accumulate,
+                              void* workspace, size_t workspace_bytes, void* stream);
 /* (sum, sum of squares) partials of a materialised bf16 [rows,C] conv output, in the layout
  * bn_finalize consumes: stats f32 [disyolo_colstats_rows(rows,C)][C][2] */
 int disyolo_colstats_rows(int64_t rows, int C);
@@ -229,12 +229,15 @@ int disyolo_bn_fold(const float* gamma, const float* beta, const float* moving_m
 int disyolo_bn_act_fwd(const void* x, const float* scale, const float* shift, const void* residual,
                        void* y, int64_t rows, int C, float alpha, void* stream);
 /* backward of y = leaky(gamma*xhat + beta), training statistics.  dy, x bf16 [rows,C];
- * writes dx bf16 and dgamma/dbeta f32.  workspace: disyolo_bn_act_bwd_workspace bytes. */
+ * writes dx bf16 and dgamma/dbeta f32.  workspace: disyolo_bn_act_bwd_workspace bytes.
+ * shortcut_grad (bf16 [rows,C] or NULL): the gradient buffer of the layer a residual shortcut comes from
+ * (res_conv_bn, :148-151): it receives dy (shortcut_accumulate = 0) or dy + itself (1) in the same pass that
+ * reads dy for dx -- what disyolo_add_bf16(dy, shortcut_grad) would do in a launch of its own. */
 size_t disyolo_bn_act_bwd_workspace(int64_t rows, int C);
 int disyolo_bn_act_bwd(const void* dy, const void* x, const float* scale, const float* shift,
                        const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
-                       int64_t rows, int C, float alpha, void* workspace, size_t workspace_bytes,
-                       void* stream);
+                       int64_t rows, int C, float alpha, void* shortcut_grad, int shortcut_accumulate,
+                       void* workspace, size_t workspace_bytes, void* stream);
 /* the same when the per-channel sums (sum g, sum g*xhat) over disjoint row sets are already in
  * `partials` f32 [part_rows][C][2]: written by the data-gradient conv that produced dy, with
  * DISYOLO_CONV_BN_BWD_STATS (part_rows = disyolo_conv2d_stats_rows of that conv). */
@@ -242,7 +245,8 @@ size_t disyolo_bn_act_bwd_partials_workspace(int C);
 int disyolo_bn_act_bwd_partials(const void* dy, const void* x, const float* scale, const float* shift,
                                 const float* mean, const float* rstd, void* dx, float* dgamma,
                                 float* dbeta, int64_t rows, int C, float alpha, const float* partials,
-                                int part_rows, void* workspace, size_t workspace_bytes, void* stream);
+                                int part_rows, void* shortcut_grad, int shortcut_accumulate, void* workspace,
+                                size_t workspace_bytes, void* stream);
 
 /* ---- small data-movement ops of the backward pass ---- */
 /* dst[b,y,x,c] = sum of the 2x2 block of src (gradient of resize_nearest_neighbor x2),

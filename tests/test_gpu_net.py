@@ -513,3 +513,35 @@ def test_recorded_training_overfits_one_batch(dev, stage):
     losses = [float(net.train_step(None).cpu()) for _ in range(80)]
     assert all(np.isfinite(losses)), losses
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+
+
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_bn_backward_carries_the_shortcut_gradient(dev, accumulate):
+    """bn_act_bwd(shortcut_grad=...) == bn_act_bwd + add_bf16: the residual shortcut's gradient buffer receives
+    dy (or dy + its previous content, rounded to bf16 once like the stand-alone add) and dx / dgamma / dbeta do
+    not change -- bit for bit."""
+    g0 = torch.Generator().manual_seed(21)
+    rows, C = 2048 + 24, 96
+    x = (torch.randn(rows, C, generator=g0) * 1.3).to(torch.bfloat16).to(dev)
+    dy = torch.randn(rows, C, generator=g0).to(torch.bfloat16).to(dev)
+    prev = torch.randn(rows, C, generator=g0).to(torch.bfloat16).to(dev)
+    mean = x.float().mean(0)
+    rstd = 1.0 / torch.sqrt(x.float().var(0, unbiased=False) + 1e-5)
+    scale = (torch.rand(C, generator=g0) + 0.5).to(dev) * rstd
+    shift = (torch.randn(C, generator=g0) * 0.2).to(dev) - mean * scale
+    ws = L.Workspace(dev)
+    outs = []
+    for fused in (False, True):
+        dx, dgamma, dbeta, sc = torch.empty_like(x), torch.empty(C, device=dev), torch.empty(C, device=dev), prev.clone()
+        if fused:
+            L.bn_act_bwd(dy, x, scale, shift, mean, rstd, dx, dgamma, dbeta, rows, C, ws, 0.1, shortcut_grad=sc,
+                         shortcut_accumulate=accumulate)
+        else:
+            L.bn_act_bwd(dy, x, scale, shift, mean, rstd, dx, dgamma, dbeta, rows, C, ws, 0.1)
+            L.add_bf16(dy, sc, accumulate=accumulate)
+        torch.cuda.synchronize()
+        outs.append((dx, dgamma, dbeta, sc))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    want = (dy.float() + prev.float()).to(torch.bfloat16) if accumulate else dy
+    assert torch.equal(outs[1][3], want)
