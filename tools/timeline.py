@@ -1,15 +1,14 @@
 """Per-lane timeline of ONE recorded step from a rocprofv3 --kernel-trace CSV:
-python tools/timeline.py <kernel_trace.csv>   (uses the last complete step = between two adam kernels)"""
+python tools/timeline.py <kernel_trace.csv>   (uses the last complete step = between two optimizer-finish kernels)"""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     r["s"] = int(r["Start_Timestamp"]); r["e"] = int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
-adam = [i for i, r in enumerate(rows) if "adam_fused_kernel" in r["Kernel_Name"]]
+adam = [i for i, r in enumerate(rows) if "adam_fused_tail_kernel" in r["Kernel_Name"]]   # one per step (the sweeps are many)
 i0, i1 = (adam[-3], adam[-2]) if len(adam) >= 3 else (adam[-2], adam[-1])
 # a step = kernels after adam(i0)'s pack kernel .. adam(i1) + pack
-step = rows[i0 + 1:i1 + 2]
-step = [r for r in step if "pack_all" not in r["Kernel_Name"] or r["s"] > rows[i1]["s"]]
+step = rows[i0 + 1:i1 + 1]
 t0 = min(r["s"] for r in step); t1 = max(r["e"] for r in step)
 print("step wall %.1f us, %d kernels" % ((t1 - t0) / 1e3, len(step)))
 byq = collections.defaultdict(list)
@@ -29,7 +28,7 @@ def first(name):
     for r in step:
         if name in r["Kernel_Name"]: return (r["s"] - t0) / 1e3
     return None
-for name in ("conv_first", "yolo_loss_kernel", "bn_bwd_finalize", "adam_fused_kernel"):
+for name in ("conv_first", "yolo_loss_kernel", "bn_bwd_finalize", "adam_fused_tail_kernel"):
     print("first %-20s at %8.1f us" % (name, first(name) or -1))
 # per-queue per-kernel-class totals
 for q, rs in byq.items():
@@ -48,7 +47,7 @@ for g in sorted(gaps, reverse=True)[:12]:
     print("  %.1f us after %s -> %s" % (g[0] / 1e3, g[1], g[2]))
 # backward window: per-queue busy
 tb = [r for r in step if "bn_bwd_finalize" in r["Kernel_Name"]][0]["s"]
-ta = [r for r in step if "adam_fused_kernel" in r["Kernel_Name"]][0]["s"]
+ta = [r for r in step if "adam_fused_tail_kernel" in r["Kernel_Name"]][0]["s"]
 for q, rs in byq.items():
     w = [r for r in rs if r["s"] >= tb and r["e"] <= ta]
     f = [r for r in rs if r["e"] <= tb]
