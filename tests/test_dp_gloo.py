@@ -20,7 +20,8 @@ from disyolo_amd.net import YOLONet
 def _worker(rank, world, port, out, stage, wire):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     torch.set_num_threads(2)
     net = YOLONet(training=True, stage=stage, seed=10 + rank, plan_only=True)      # different init per rank
     w_before = net.arena.clone()

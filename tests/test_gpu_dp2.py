@@ -49,9 +49,12 @@ def _worker(rank, world, port, out, stage, sync_bn=False):
     import disyolo_amd  # noqa: F401
     import disyolo_oracle as O
     from disyolo_amd.dp import enable_data_parallel
+    import datetime
+    import faulthandler
+    faulthandler.dump_traceback_later(240, exit=False)         # a stuck rank says where
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     dev = torch.device("cuda:0")
     net = _make_net(stage, 10 + rank, dev)            # different initialisation per rank
     _seed_heads(net, 50 + rank)
@@ -105,6 +108,29 @@ def _worker(rank, world, port, out, stage, sync_bn=False):
     dist.destroy_process_group()
 
 
+def _run_ranks(args, world=2, limit=400):
+    """mp.spawn with a deadline: two ranks that do not finish within `limit` seconds are terminated and the test
+    FAILS (a hang must not take the whole suite with it)."""
+    import time
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(rank, world) + tuple(args), daemon=True) for rank in range(world)]
+    for p in procs:
+        p.start()
+    deadline = time.time() + limit
+    for p in procs:
+        p.join(max(0.0, deadline - time.time()))
+    stuck = [p for p in procs if p.is_alive()]
+    for p in stuck:
+        p.terminate()
+    for p in stuck:
+        p.join(10)
+        if p.is_alive():
+            p.kill()
+    assert not stuck, "%d of %d ranks still running after %d s" % (len(stuck), world, limit)
+    codes = [p.exitcode for p in procs]
+    assert all(c == 0 for c in codes), "rank exit codes %s" % codes
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -117,7 +143,7 @@ def _free_port():
 def test_two_ranks_on_one_gpu_over_gloo(dev, tmp_path, stage):
     import disyolo_oracle as O
     out = str(tmp_path / "dp2.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out, stage), nprocs=2, join=True)
+    _run_ranks((_free_port(), out, stage))
     res = torch.load(out)
     assert res["bcast_equal"] and res["differed"] == [False, True] and res["finite"]
     assert res["buckets"] >= (3 if stage == 2 else 2)
@@ -166,7 +192,7 @@ def test_sync_bn_two_ranks_train_like_one_process_with_the_global_batch(dev, tmp
         out = str(tmp_path / ("dp2s%d.pt" % sync))
         os.environ["DP2_THRESH"] = "0.999"
         try:
-            mp.spawn(_worker, args=(2, _free_port(), out, stage, sync), nprocs=2, join=True)
+            _run_ranks((_free_port(), out, stage, sync))
         finally:
             os.environ.pop("DP2_THRESH")
         res[sync] = torch.load(out)
