@@ -20,6 +20,7 @@ from disyolo_amd.net import YOLONet
 def _worker(rank, world, port, out, stage, wire):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # loopback: no resolution of the container's hostname
     import datetime
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     torch.set_num_threads(2)

@@ -54,6 +54,7 @@ def _worker(rank, world, port, out, stage, sync_bn=False):
     faulthandler.dump_traceback_later(240, exit=False)         # a stuck rank says where
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # loopback: no resolution of the container's hostname
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     dev = torch.device("cuda:0")
     net = _make_net(stage, 10 + rank, dev)            # different initialisation per rank
