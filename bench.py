@@ -148,6 +148,7 @@ def bench_infer(args, dev, world, rank):
                             "frac_of_mfma_peak": round(gf * value / world / 1e3 / MFMA_PEAK_TFLOPS, 4)},
             "reference_published": "README.md:23: ~0.1 s/image (10 img/s) on i7-7700 + GTX 1060, incl. host mask crop"}))
     if world > 1:
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 
@@ -417,6 +418,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.stage, S)
         emit(out)
     if use_dp:
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

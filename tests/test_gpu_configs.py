@@ -180,6 +180,8 @@ def one_rank_rccl(dev):
     os.environ.setdefault("MASTER_PORT", "29541")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     yield dist
+    # (a communicator torn down while device work is still queued is a classic way to hang: drain first)
+    torch.cuda.synchronize()
     dist.destroy_process_group()
 
 
