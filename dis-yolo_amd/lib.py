@@ -54,16 +54,16 @@ _SIGS = {
     "disyolo_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "disyolo_conv2d_tile": (C.c_int, [C.POINTER(ConvDesc)] + [C.POINTER(C.c_int)] * 4),
     "disyolo_conv_first_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
-    "disyolo_conv2d_wgrad_workspace": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "disyolo_conv2d_wgrad_workspace": (C.c_size_t, [C.POINTER(ConvDesc), C.c_int]),
     "disyolo_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
-                                       C.c_size_t, C.c_void_p]),
+                                       C.c_size_t, C.c_int, C.c_void_p]),
     "disyolo_conv2d_fp8_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                          C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "disyolo_conv_first_fwd_fp8": (C.c_int, [C.c_void_p] * 5 + [C.c_float] + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "disyolo_quant_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "disyolo_dequant_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "disyolo_pack_weights_fp8": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
-    "disyolo_conv2d_wgrad_plan": (C.c_int, [C.POINTER(ConvDesc)] + [C.POINTER(C.c_int)] * 4),
+    "disyolo_conv2d_wgrad_plan": (C.c_int, [C.POINTER(ConvDesc), C.c_int] + [C.POINTER(C.c_int)] * 4),
     "disyolo_conv_first_wgrad_workspace": (C.c_size_t, [C.c_int] * 4),
     "disyolo_conv_first_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "disyolo_image_pad8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -328,11 +328,16 @@ class ConvTuner:
         self.candidates = tuple(candidates)
         self.current = 0              # tile code of the running pass (0 = launcher heuristic)
         self.events = {}              # (key, cand) -> [(start, end)]
+        self.stats_rows = {}          # stats buffer address -> partial-sum rows the last launch into it wrote
 
     def launch(self, d: ConvDesc) -> None:
         key = conv_shape_key(d)
         keep = d.tile
         d.tile = self.current
+        if d.stats:
+            # the number of batch-norm partial-sum rows depends on the tile: the finalize that follows must sum
+            # exactly the rows THIS candidate writes, or the tuning passes run on garbage statistics
+            self.stats_rows[d.stats] = conv2d_stats_rows(d)
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
@@ -480,35 +485,43 @@ def conv_first_fwd(images, w_hwio, scale, shift, y, alpha=0.1) -> None:
                                          alpha, _stream()), "conv_first_fwd")
 
 
-def conv2d_wgrad(d: ConvDesc, dy, dy_ld: int, dw, ws: Workspace) -> None:
-    need = load().disyolo_conv2d_wgrad_workspace(C.byref(d))
+WGRAD_IM2COL, WGRAD_PARTIAL_ONLY, WGRAD_REDUCE_ONLY = 1, 2, 4
+
+
+def wgrad_stages(n: int) -> int:
+    """opts bits for the im2col weight-gradient kernel's pipeline depth (2..4 stages)"""
+    return (n - 1) << 4
+
+
+def conv2d_wgrad_workspace(d: ConvDesc, opts: int = 0) -> int:
+    return load().disyolo_conv2d_wgrad_workspace(C.byref(d), opts)
+
+
+def conv2d_wgrad(d: ConvDesc, dy, dy_ld: int, dw, ws: Workspace, opts: int = 0) -> None:
+    """dw = weight gradient of the conv ``d`` describes.  ``d.tile`` is not read (it belongs to conv2d_fwd);
+    ``opts`` = WGRAD_* tuning / timing switches, 0 in the product path."""
+    need = conv2d_wgrad_workspace(d, opts)
     buf = ws.get(need)
-    if TIMER is not None:
+
+    def call(o):
+        _check(load().disyolo_conv2d_wgrad(C.byref(d), _p(dy), dy_ld, _p(dw), _p(buf), buf.numel(), o, _stream()),
+               "conv2d_wgrad")
+    if TIMER is not None and not (opts & (WGRAD_PARTIAL_ONLY | WGRAD_REDUCE_ONLY)):
         # the partial-sum kernel and the slab reduction as two timed launches (same work, same order)
-        kind, tn, ring, splits = conv2d_wgrad_plan(d)
+        kind, tn, ring, splits = conv2d_wgrad_plan(d, opts)
         waves = 8 if os.environ.get("DISYOLO_WG3_WAVES") == "8" else 4
         name = ("conv_wgrad3x3_kernel<%d,%d,3,%d>" % (tn, ring, waves)) if kind == 1 else ("conv_wgrad_kernel<%d,3>" % tn)
-        keep = d.tile
-
-        def phase(bits):
-            d.tile = keep | bits
-            try:
-                _check(load().disyolo_conv2d_wgrad(C.byref(d), _p(dy), dy_ld, _p(dw), _p(buf), buf.numel(), _stream()),
-                       "conv2d_wgrad")
-            finally:
-                d.tile = keep
-        TIMER.run(name, conv_flops(d), lambda: phase(0x200))
+        TIMER.run(name, conv_flops(d), lambda: call(opts | WGRAD_PARTIAL_ONLY))
         if splits > 1:
-            TIMER.run("slab_reduce_kernel", 0.0, lambda: phase(0x400))
+            TIMER.run("slab_reduce_kernel", 0.0, lambda: call(opts | WGRAD_REDUCE_ONLY))
         return
-    _check(load().disyolo_conv2d_wgrad(C.byref(d), _p(dy), dy_ld, _p(dw), _p(buf), buf.numel(), _stream()),
-           "conv2d_wgrad")
+    call(opts)
 
 
-def conv2d_wgrad_plan(d: ConvDesc):
+def conv2d_wgrad_plan(d: ConvDesc, opts: int = 0):
     """(kind, channel tile, ring slots, pixel splits) of the weight-gradient launch for this descriptor"""
     v = [C.c_int(0) for _ in range(4)]
-    _check(load().disyolo_conv2d_wgrad_plan(C.byref(d), *[C.byref(x) for x in v]), "conv2d_wgrad_plan")
+    _check(load().disyolo_conv2d_wgrad_plan(C.byref(d), opts, *[C.byref(x) for x in v]), "conv2d_wgrad_plan")
     return tuple(x.value for x in v)
 
 

@@ -179,6 +179,10 @@ class YOLONet(object):
         self._side_streams = {}  # id(recorded list) -> its side lane as a torch stream
         self._progs = None      # [parity] -> (list, marks, bwd_end) of the pipelined step
         self.use_side_lane = os.environ.get("DISYOLO_SIDE_LANE", "1") != "0"
+        # debug mode of the fused batch-norm backward (set to a list): every layer whose backward sums come from the
+        # data-gradient conv's epilogue ALSO runs the plain column reduction on the same gradient (eager steps only) and
+        # appends the relative differences of dx / dgamma / dbeta
+        self.bn_fuse_check = None
         if os.environ.get("DISYOLO_EXP_SKIP_WGRAD") in ("1", "2"):
             print("disyolo: DISYOLO_EXP_SKIP_WGRAD is set -- weight gradients are NOT computed (timing experiment)", file=sys.stderr)
         # weight gradients of the last layers of the backward pass stay on the main lane (tuned below)
@@ -420,13 +424,11 @@ class YOLONet(object):
             need = 1 << 20
             for l in self.layers:
                 if l.wgrad_desc is not None:
-                    import ctypes
-                    need = max(need, L.load().disyolo_conv2d_wgrad_workspace(ctypes.byref(l.wgrad_desc)))
+                    need = max(need, L.conv2d_wgrad_workspace(l.wgrad_desc))
                 if l.dx is not None and l.kind != "lin":
                     need = max(need, L.load().disyolo_bn_act_bwd_workspace(B * l.Ho * l.Wo, l.cout))
             if not l1.lock:
-                import ctypes
-                need = max(need, L.load().disyolo_conv2d_wgrad_workspace(ctypes.byref(self._wgrad1_desc)))
+                need = max(need, L.conv2d_wgrad_workspace(self._wgrad1_desc))
             self.ws.get(int(need))
             self.ws_aux.get(int(need))
         self.ws_det.get(int(max(L.load().disyolo_detect_workspace(B, S, self.num_class), 1 << 20)))
@@ -638,11 +640,14 @@ class YOLONet(object):
     def _bn_finalize(self, l, M: int) -> None:
         """batch statistics -> scale/shift/mean/rstd + moving statistics (yolo/yolo3_net_pos.py:90-98).  With
         SyncBN the per-channel sums are added up over the data-parallel ranks first (SURVEY.md 8e option)."""
+        rows = l.stats_rows
+        if L.TUNER is not None:
+            rows = L.TUNER.stats_rows.get(l.stats.data_ptr(), rows)     # rows the candidate tile just wrote
         if not self.sync_bn:
-            L.bn_finalize(l.stats, l.stats_rows, l.cout, M, l.gamma, l.beta, l.mm, l.mv, cfg.BN_DECAY,
+            L.bn_finalize(l.stats, rows, l.cout, M, l.gamma, l.beta, l.mm, l.mv, cfg.BN_DECAY,
                           cfg.BN_EPSILON, l.scale, l.shift, l.mean, l.rstd)
             return
-        L.bn_partial_sums(l.stats, l.stats_rows, l.cout, l.bn_sums)
+        L.bn_partial_sums(l.stats, rows, l.cout, l.bn_sums)
         self._sync_sums(l.bn_sums)
         L.bn_finalize_sums(l.bn_sums, l.cout, M * self.dp.world_size, l.gamma, l.beta, l.mm, l.mv, cfg.BN_DECAY,
                            cfg.BN_EPSILON, l.scale, l.shift, l.mean, l.rstd)
@@ -912,8 +917,24 @@ class YOLONet(object):
                                         M * self.dp.world_size, l.dx, l.dgamma, l.dbeta, M, l.cout, self.ws, cfg.ALPHA, **kw)
                 elif l.bwd_part_rows:
                     # the patch conv that made l.grad final left the batch-norm backward sums, one row per patch
+                    ref = None
+                    if self.bn_fuse_check is not None and self._rec is None:
+                        # debug mode: the plain three-kernel backward on the same gradient first, into scratch
+                        ref = (torch.empty_like(l.dx), torch.empty_like(l.dgamma), torch.empty_like(l.dbeta))
+                        L.bn_act_bwd(l.grad, l.raw, l.scale, l.shift, l.mean, l.rstd, ref[0], ref[1], ref[2], M, l.cout,
+                                     self.ws, cfg.ALPHA)
                     L.bn_act_bwd_partials(l.grad, l.raw, l.scale, l.shift, l.mean, l.rstd, l.dx, l.dgamma, l.dbeta, M,
                                           l.cout, l.bwd_part, l.bwd_part_rows, self.ws, cfg.ALPHA, **kw)
+                    if ref is not None:
+                        torch.cuda.synchronize()
+
+                        def rel(a, b):
+                            a, b = a.double().flatten(), b.double().flatten()
+                            return float((a - b).norm() / (b.norm() + 1e-30))
+                        self.bn_fuse_check.append({"layer": l.idx, "rows": l.bwd_part_rows, "shape": (l.Ho, l.Wo, l.cout),
+                                                   "dx": rel(l.dx, ref[0]), "dgamma": rel(l.dgamma, ref[1]),
+                                                   "dbeta": rel(l.dbeta, ref[2]),
+                                                   "finite": bool(torch.isfinite(l.dx.float()).all())})
                 else:
                     L.bn_act_bwd(l.grad, l.raw, l.scale, l.shift, l.mean, l.rstd, l.dx, l.dgamma, l.dbeta, M, l.cout,
                                  self.ws, cfg.ALPHA, **kw)

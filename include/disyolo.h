@@ -130,10 +130,18 @@ int disyolo_conv_first_fwd(const float* images, const float* w_hwio, const float
  * dw[kh,kw,ci,co] (f32 HWIO, overwritten) = sum_m xcol[m,(kh,kw,ci)] * dy[m,co].
  * Uses d->x0/x1 (the layer input, same gather as forward) and `dy` bf16 [B*Ho*Wo, dy_ld]
  * (dy_ld >= Cout, multiple of 8; columns >= Cout are ignored).
- * workspace: disyolo_conv2d_wgrad_workspace(d) bytes. */
-size_t disyolo_conv2d_wgrad_workspace(const disyolo_conv_desc* d);
+ * workspace: disyolo_conv2d_wgrad_workspace(d, opts) bytes.
+ * The descriptor's `tile` field is NOT read (it pins the forward / data-gradient tile of the same GEMM shape);
+ * `opts` = 0 for the product path, or DISYOLO_WGRAD_* bits for tuning and per-kernel timing. */
+enum {
+  DISYOLO_WGRAD_IM2COL = 1,       /* force the im2col kernel where the tap-fused 3x3 kernel would run   */
+  DISYOLO_WGRAD_PARTIAL_ONLY = 2, /* launch only the partial-sum kernel (dw is NOT written if it splits) */
+  DISYOLO_WGRAD_REDUCE_ONLY = 4,  /* launch only the slab reduction (workspace must hold the slabs)      */
+  DISYOLO_WGRAD_STAGES_MASK = 0x30 /* im2col kernel pipeline depth: (n << 4), n = 1..3 -> 2..4 stages    */
+};
+size_t disyolo_conv2d_wgrad_workspace(const disyolo_conv_desc* d, int opts);
 int disyolo_conv2d_wgrad(const disyolo_conv_desc* d, const void* dy, int dy_ld, float* dw,
-                         void* workspace, size_t workspace_bytes, void* stream);
+                         void* workspace, size_t workspace_bytes, int opts, void* stream);
 /* same for the first layer (f32 image input, Cin = 3): dw f32 [3,3,3,Cout] */
 /* ---- fp8 (OCP e4m3) forward path of the inference-mode layers (BASELINE.json configs[4]; the reference
  * is f32: yolo/yolo3_net_pos.py:132-146 conv_bn with lock=True) ----
@@ -159,9 +167,8 @@ int disyolo_pack_weights_fp8(const float* w_hwio, void* w_fp8, int ksize, int Ci
 
 /* which kernel the launcher picks for this descriptor: kind 0 = im2col kernel (tile_n = channel tile),
  * 1 = tap-fused 3x3 kernel (tile_n = channel tile, ring = input ring slots); splits = pixel splits
- * (f32 slabs summed by slab_reduce when > 1).  desc.tile bit 0x100 forces the im2col kernel; bits
- * 0x200 / 0x400 launch only the partial-sum kernel / only the slab reduction (per-kernel timing). */
-int disyolo_conv2d_wgrad_plan(const disyolo_conv_desc* d, int* kind, int* tile_n, int* ring, int* splits);
+ * (f32 slabs summed by slab_reduce when > 1).  opts: DISYOLO_WGRAD_* as passed to disyolo_conv2d_wgrad. */
+int disyolo_conv2d_wgrad_plan(const disyolo_conv_desc* d, int opts, int* kind, int* tile_n, int* ring, int* splits);
 size_t disyolo_conv_first_wgrad_workspace(int B, int H, int W, int Cout);
 int disyolo_conv_first_wgrad(const float* images, const void* dy, float* dw, int B, int H, int W,
                              int Cout, void* workspace, size_t workspace_bytes, void* stream);

@@ -9,7 +9,7 @@ from disyolo_amd.net import build_topology
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 576
-variants = [int(t, 0) for t in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0x100, 0]   # 0x100 = im2col kernel, 0 = planner's pick
+variants = [int(t, 0) for t in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 0]   # opts: 1 = im2col kernel (DISYOLO_WGRAD_IM2COL), 0 = planner's pick
 first = int(sys.argv[4]) if len(sys.argv) > 4 else 53
 dev = torch.device("cuda:0")
 layers = build_topology(3, 3)
@@ -37,14 +37,14 @@ for key, idxs in sorted(shapes.items(), key=lambda kv: -kv[0][0]):
     fl = 2.0 * B * Ho * Ho * cout * cin * k * k
     row = []
     for v in variants:
-        d = L.make_conv_desc(x0, dy, yd, k, s, tile=v)
+        d = L.make_conv_desc(x0, dy, yd, k, s)
         for _ in range(3):
-            L.conv2d_wgrad(d, dy, ld, dw, ws)
+            L.conv2d_wgrad(d, dy, ld, dw, ws, opts=v)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(20):
-            L.conv2d_wgrad(d, dy, ld, dw, ws)
+            L.conv2d_wgrad(d, dy, ld, dw, ws, opts=v)
         e1.record()
         torch.cuda.synchronize()
         dt = e0.elapsed_time(e1) / 20 * 1e-3
