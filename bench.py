@@ -126,8 +126,9 @@ def bench_infer(args, dev, world, rank):
     net = YOLONet(training=False, device=dev, image_size=S, batch_size=B, stage=1, seed=0)
     batch = synthetic_batch(B, S, seed=1234 + rank)
     net._set_inputs(batch["images"], batch["clip_window"])
+    cache = tune_cache_path(args, "infer_B%d_%d" % (B, S))
     if args.autotune == "on":
-        net.autotune()
+        net.autotune(cache=cache)
     net.build_infer_program(graph=(args.mode in ("auto", "graph")))
     for _ in range(args.warmup):
         net.infer()
@@ -142,6 +143,8 @@ def bench_infer(args, dev, world, rank):
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "infer_B%d_%dx%d_3class" % (B, S, S), "images_per_gpu": B,
                        "step_driver": "graph" if net._infer_graph is not None else "program",
+                       "conv_tiles": ("table %s" % os.path.relpath(cache, ROOT)) if cache else
+                                     ("autotuned in-sequence at setup" if args.autotune == "on" else "launcher heuristic"),
                        "detections_in_batch": int(net.det_count.sum().item())},
             "model_flops": {"fwd_gflop_per_image": round(gf, 2),
                             "achieved_tflops_per_gpu": round(gf * value / world / 1e3, 1),
@@ -150,6 +153,16 @@ def bench_infer(args, dev, world, rank):
     if world > 1:
         torch.cuda.synchronize()
         dist.destroy_process_group()
+
+
+def tune_cache_path(args, workload: str):
+    """the committed tile table of this workload, a user-named file, or None (tune live)"""
+    if args.tune_cache == "none" or args.autotune != "on":
+        return None
+    if args.tune_cache != "auto":
+        return args.tune_cache
+    p = os.path.join(ROOT, "profiles", "tune_%s.json" % workload)
+    return p if os.path.exists(p) else None
 
 
 def timed_region(step, steps: int, world: int, dev) -> float:
@@ -190,12 +203,14 @@ def secondary_measurements(args, dev):
     out = {}
     S = args.size
     common = ["--size", str(S), "--steps", "10", "--warmup", "3", "--repeats", "5", "--autotune", args.autotune,
-              "--no-secondary", "--no-cpu-baseline", "--no-kernel-events"]
+              "--tune-cache", args.tune_cache, "--no-secondary", "--no-cpu-baseline", "--no-kernel-events"]
 
     def child(extra):
         r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra + common, stdout=subprocess.PIPE,
                            stderr=subprocess.DEVNULL, timeout=600)
         lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+        if lines and json.loads(lines[-1]).get("error"):
+            raise RuntimeError(json.loads(lines[-1])["error"])       # e.g. a non-finite loss: no throughput is taken from it
         if r.returncode != 0 or not lines:
             raise RuntimeError("child bench exited with %d" % r.returncode)
         return json.loads(lines[-1])
@@ -206,7 +221,9 @@ def secondary_measurements(args, dev):
         out["train_stage2"] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
                                "ms_per_step": d["ms_per_step"], "steps": d["steps"], "repeats": d.get("repeats"),
                                "frac_of_mfma_peak": round(gf * d["value"] / 1e3 / MFMA_PEAK_TFLOPS, 4),
-                               "final_total_loss": d["config"].get("final_total_loss"), "process": "child"}
+                               "loss_first": d["config"].get("loss_first"), "loss_last": d["config"].get("loss_last"),
+                               "final_total_loss": d["config"].get("final_total_loss"),
+                               "conv_tiles": d["config"].get("conv_tiles"), "process": "child"}
     except Exception as e:   # a secondary line must never cost the headline
         out["train_stage2"] = {"error": repr(e)[:200]}
     try:
@@ -261,7 +278,11 @@ def main():
     ap.add_argument("--autotune", default="on", choices=("on", "off"),
                     help="time the conv tile candidates inside the layer sequence before recording the step "
                          "(setup, outside the timed region)")
-    ap.add_argument("--tune-cache", default=None, help="JSON file to load the autotuned tiles from / save them to")
+    ap.add_argument("--tune-cache", default="auto",
+                    help="JSON file to load the autotuned tiles from / save them to.  'auto' (default): the committed "
+                         "table profiles/tune_<workload>.json when there is one for this workload (the run is then "
+                         "bit-reproducible box to box and its losses are a regression canary), else tune live; "
+                         "'none': always tune live")
     ap.add_argument("--force-dp", action="store_true",
                     help="initialise RCCL and run the bucketed gradient all-reduce path even with one rank (self-test)")
     ap.add_argument("--sync-bn", action="store_true",
@@ -306,9 +327,11 @@ def main():
         net.calibrate_fp8()        # static per-tensor scales (setup, outside the timed region)
     torch.manual_seed(1234 + rank)
     gen = None                     # default CUDA generator
+    workload = "train_B%d_%d_stage%d%s" % (B, S, args.stage, "" if args.dtype == "bf16" else "_fp8")
+    cache = tune_cache_path(args, workload)
     if args.autotune == "on":
         t_tune = time.perf_counter()
-        picks = net.autotune(cache=args.tune_cache)
+        picks = net.autotune(cache=cache)
         if rank == 0:
             print("autotune %.1f s: %d of %d conv shapes moved off the launcher heuristic"
                   % (time.perf_counter() - t_tune, sum(1 for v in picks.values() if v), len(picks)), file=sys.stderr)
@@ -321,8 +344,11 @@ def main():
 
     net.shuffle_seed = 1234 + rank   # tf.random_shuffle of the mask-loss RoIs: on the device, every step
 
+    n_trained = [0]
+
     def step():
         net.train_step(None, want_loss=False)
+        n_trained[0] += 1
 
     # per-kernel durations for the roofline: HIP events around every conv launch over K eager
     # steps of the same workload (events cannot time nodes inside a graph replay; the kernels
@@ -347,10 +373,25 @@ def main():
         net.build_program(graph=(mode == "graph"), pipeline_backbone=pipe)
         if pipe:
             net.prime_pipeline()       # backbone of the first batch, outside the timed region
-    for _ in range(args.warmup):
+    # losses are read OUTSIDE the timed regions: after the first recorded step, after the warm-up, after every region
+    loss_trace = []
+    for i in range(args.warmup):
         step()
-    dt, regions = repeated(step, args.steps, args.repeats, world, dev)
-    loss = float(net.total_loss().cpu())
+        if i == 0:
+            loss_trace.append(float(net.total_loss().cpu()))
+    if args.warmup > 1:
+        loss_trace.append(float(net.total_loss().cpu()))
+    regions = []
+    for _ in range(max(1, args.repeats)):
+        regions.append(timed_region(step, args.steps, world, dev))
+        loss_trace.append(float(net.total_loss().cpu()))
+    dt = float(np.median(regions))
+    loss = loss_trace[-1]
+    finite = bool(np.all(np.isfinite(loss_trace))) and bool(torch.isfinite(net.arena).all())
+    if world > 1:
+        f = torch.tensor([1.0 if finite else 0.0], device=dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        finite = bool(f.item() > 0)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -370,13 +411,28 @@ def main():
                        "stage": "1: conv1-52 locked (shipped reference source)" if args.stage == 1 else
                                 "2: all 82 layers trainable",
                        "parallelism": "dp%d%s" % (world, "+syncbn" if (use_dp and args.sync_bn) else ""), "rccl_buckets": (len(net.dp.buckets) + 1) if net.dp else 0, "optimizer": "adam(tf-form) lr=1e-4", "step_driver": mode,
-                       "conv_tiles": "autotuned in-sequence at setup" if args.autotune == "on" else "launcher heuristic",
+                       "conv_tiles": ("table %s" % os.path.relpath(cache, ROOT)) if cache else
+                                     ("autotuned in-sequence at setup" if args.autotune == "on" else "launcher heuristic"),
                        "backbone_pipeline": bool(args.stage == 1 and mode == "program" and args.pipeline == "on"),
-                       "final_total_loss": round(loss, 4)},
+                       "loss_first": round(loss_trace[0], 4) if np.isfinite(loss_trace[0]) else None,
+                       "loss_last": round(loss, 4) if np.isfinite(loss) else None,
+                       "final_total_loss": round(loss, 4) if np.isfinite(loss) else None,
+                       "steps_trained": n_trained[0]},
             "model_flops": {"train_gflop_per_image": round(train_gflop, 1),
                             "achieved_tflops_per_gpu": round(train_gflop * value / world / 1e3, 1),
                             "frac_of_mfma_peak": round(train_gflop * value / world / 1e3 / MFMA_PEAK_TFLOPS, 4)},
         }
+        if not finite:
+            # a diverged run does less work (NaN scores empty the NMS and the mask-loss chain): its time is not a
+            # measurement.  No throughput is reported and the process fails.
+            out["error"] = "non-finite loss or weights (loss trace %s)" % [None if not np.isfinite(v) else round(v, 2) for v in loss_trace]
+            out["value"] = None
+            out["ms_per_step"] = None
+            emit(out)
+            if use_dp:
+                torch.cuda.synchronize()
+                dist.destroy_process_group()
+            sys.exit(3)
         tb = bound_model(B, S, args.stage)
         out["bound_model"] = {"t_bound_ms": round(tb * 1e3, 3), "achieved_vs_bound": round(tb * 1e3 / ms, 4),
                               "definition": "sum over kernels of max(FLOP/2.5 PF, algorithmic bytes/8 TB/s): convs "

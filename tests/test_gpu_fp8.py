@@ -170,6 +170,6 @@ def test_fp8_backbone_training_step_records_and_replays_bit_identically(dev):
     l1 = [float(nets[1].train_step(None).cpu()) for _ in range(3)]
     torch.cuda.synchronize()
     np.testing.assert_array_equal(l0, l1)
-    assert torch.equal(nets[0].arena, nets[1].arena) and np.isfinite(l0).sum() >= 2
+    assert torch.equal(nets[0].arena, nets[1].arena) and np.all(np.isfinite(l0)), l0
     # the trainable layers really consumed the fp8 backbone's bf16 hand-over (skip / trunk outputs)
     assert float(nets[0].by_idx[52].act.float().abs().max()) > 0 and float(nets[0].by_idx[26].act.float().abs().max()) > 0
