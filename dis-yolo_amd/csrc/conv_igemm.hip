@@ -701,10 +701,9 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
   // following ones are spread over the 9 taps of the slice being multiplied, so a wave's DMA
   // issue (~60 cycles each) overlaps its own MFMAs instead of preceding them.
   constexpr int NDMA = AIM + BIM, DPT = (NDMA + 8) / 9;
-  auto issue_one = [&]<int I>(std::integral_constant<int, I>, int c, int stage) {
+  auto issue_one = [&]<int I>(std::integral_constant<int, I>, unsigned cs2 /* byte offset of the channel slice */, int stage) {
     if constexpr (I < NDMA) {
       const unsigned sbase = lds0 + stage * STB + wave * 1024;
-      const unsigned cs2 = (unsigned)c * 64u;      // 32 channels x 2 bytes
       if constexpr (I < AIM)
         dma16<I * SLAB>(a_off[I], srd0, cs2, sbase);
       else
@@ -713,7 +712,7 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
   };
   auto issue = [&](int c, int stage) {
     [&]<int... I>(std::integer_sequence<int, I...>) {
-      (issue_one(std::integral_constant<int, I>{}, c, stage), ...);
+      (issue_one(std::integral_constant<int, I>{}, (unsigned)c * 64u, stage), ...);
     }(std::make_integer_sequence<int, NDMA>{});
   };
 
@@ -751,47 +750,57 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
 
   const int nch = p.Cin >> 5;
   issue(0, 0);
+  // Fragment registers are double-buffered over the taps: the LDS reads of tap T+1 are issued before the MFMAs of tap
+  // T, so a group of MFMAs never waits for the round trip of its own operands.  (Round 2 read, waited lgkmcnt(0) and
+  // multiplied one M fragment at a time, inside a wave-uniform branch per fragment: every 4 MFMAs paid a full LDS
+  // latency and the scheduler could not move anything across the branches -- MFMA pipe 25-28 % busy.)  The slice body
+  // is branch-free: a wave that owns fewer than FW fragments multiplies a dummy one (pixel 0 of the patch, never
+  // stored; the block is as slow as its fullest wave anyway), and the DMAs issued during the LAST slice get an
+  // out-of-range scalar offset -- no memory traffic, zeros into the stage nobody reads again -- instead of a branch.
+  bf16x8 wfr[2][NI], xfr[2][FW];
+  auto load_frags = [&]<int TAP>(std::integral_constant<int, TAP>, const char* st) {
+    constexpr int kh = TAP / 3, kw = TAP % 3, bi = TAP & 1;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) wfr[bi][j] = *reinterpret_cast<const bf16x8*>(st + wb[j] + TAP * BN * 64);
+#pragma unroll
+    for (int t = 0; t < FW; ++t) {
+      const int hp = hp0[t] + kh * HW_ + kw;
+      xfr[bi][t] = *reinterpret_cast<const bf16x8*>(st + hp * 64 + swz_any(hp, fchunk) * 16);
+    }
+  };
   for (int c = 0; c < nch; ++c) {
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // slice c has landed for everyone; everyone is done with slice c-1
     asm volatile("" ::: "memory");
-    const bool more = c + 1 < nch;
+    const unsigned cs_next = (c + 1 < nch) ? (unsigned)(c + 1) * 64u : OOB;
+    const int stage_next = (c + 1) & 1;
     const char* st = smem + (c & 1) * STB;
+    load_frags(std::integral_constant<int, 0>{}, st);
     auto tap_body = [&]<int TAP>(std::integral_constant<int, TAP>) {
-      constexpr int kh = TAP / 3, kw = TAP % 3;
-      bf16x8 wf[NI];
+      constexpr int bi = TAP & 1;
+      if constexpr (TAP < 8) load_frags(std::integral_constant<int, TAP + 1>{}, st);
+      __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise sinks the reads back next to their uses)
+      [&]<int... D>(std::integer_sequence<int, D...>) {
+        (issue_one(std::integral_constant<int, TAP * DPT + D>{}, cs_next, stage_next), ...);
+      }(std::make_integer_sequence<int, DPT>{});
 #pragma unroll
-      for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(st + wb[j] + TAP * BN * 64);
+      for (int t = 0; t < FW; ++t)
 #pragma unroll
-      for (int t = 0; t < FW; ++t) {
-        if (t < nf_w) {
-          const int hp = hp0[t] + kh * HW_ + kw;
-          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(st + hp * 64 + swz_any(hp, fchunk) * 16);
-#pragma unroll
-          for (int j = 0; j < NI; ++j) {
+        for (int j = 0; j < NI; ++j) {
 #ifdef DY_PROBE
-            if (p.flags & 0x10000) {
-              asm volatile("" ::"v"(xf), "v"(wf[j]));
-              continue;
-            }
-#endif
-            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf, acc[t][j], 0, 0, 0);
+          if (p.flags & 0x10000) {
+            asm volatile("" ::"v"(xfr[bi][t]), "v"(wfr[bi][j]));
+            continue;
           }
-        }
-      }
-#ifdef DY_PROBE
-      if (p.flags & 0x4000) return;
 #endif
-      if (more) {
-        [&]<int... D>(std::integer_sequence<int, D...>) {
-          (issue_one(std::integral_constant<int, TAP * DPT + D>{}, c + 1, (c + 1) & 1), ...);
-        }(std::make_integer_sequence<int, DPT>{});
-      }
+          acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[bi][j], xfr[bi][t], acc[t][j], 0, 0, 0);
+        }
     };
     [&]<int... T>(std::integer_sequence<int, T...>) {
       (tap_body(std::integral_constant<int, T>{}), ...);
     }(std::make_integer_sequence<int, 9>{});
   }
+  wait_vmcnt<0>();   // the zero-fill DMAs of the last slice: the epilogue reuses the stages
   __syncthreads();
 
   // ---- epilogue.  acc[t][j][r]: patch pixel q_of[t] (lane & 15), channel n0 + j*16 + 4*(lane>>4) + r

@@ -802,8 +802,8 @@ def lane_mark(lane: int) -> int:
     return r
 
 
-def lane_wait(mark: int, lane: int) -> None:
-    if mark >= 0:
+def lane_wait(mark: Optional[int], lane: int) -> None:
+    if mark is not None and mark >= 0:
         _check(load().disyolo_cmdlist_wait(mark, lane), "cmdlist_wait")
 
 
