@@ -700,7 +700,7 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
   // DMA i of a slice: i < AIM halo, else weights.  The first slice is issued in one go; the
   // following ones are spread over the 9 taps of the slice being multiplied, so a wave's DMA
   // issue (~60 cycles each) overlaps its own MFMAs instead of preceding them.
-  constexpr int NDMA = AIM + BIM, DPT = (NDMA + 8) / 9;
+  constexpr int NDMA = AIM + BIM, DPT = (NDMA + 4) / 5;   // the next slice's DMAs go out during the first 5 taps: they have 4 taps left to land
   auto issue_one = [&]<int I>(std::integral_constant<int, I>, unsigned cs2 /* byte offset of the channel slice */, int stage) {
     if constexpr (I < NDMA) {
       const unsigned sbase = lds0 + stage * STB + wave * 1024;

@@ -1,0 +1,2 @@
+timeout 600 python tools/bench_conv.py 8 576 16,17,18,12,3 2>&1 | grep ", 3, 1"
+timeout 600 python tools/bench_conv.py 32 576 16,17,18,12,3 2>&1 | grep ", 3, 1"
