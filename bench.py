@@ -387,6 +387,15 @@ def main():
         loss_trace.append(float(net.total_loss().cpu()))
     dt = float(np.median(regions))
     loss = loss_trace[-1]
+    dp_trace = None
+    if net.dp is not None:
+        # after the timed regions: a few steps with the exchange traced (events around every bucket's wait)
+        net.dp.trace = []
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        dp_trace = net.dp.trace_summary()
+        net.dp.trace = None
     finite = bool(np.all(np.isfinite(loss_trace))) and bool(torch.isfinite(net.arena).all())
     if world > 1:
         f = torch.tensor([1.0 if finite else 0.0], device=dev)
@@ -422,6 +431,8 @@ def main():
                             "achieved_tflops_per_gpu": round(train_gflop * value / world / 1e3, 1),
                             "frac_of_mfma_peak": round(train_gflop * value / world / 1e3 / MFMA_PEAK_TFLOPS, 4)},
         }
+        if dp_trace is not None:
+            out["dp_exchange"] = dp_trace
         if not finite:
             # a diverged run does less work (NaN scores empty the NMS and the mask-loss chain): its time is not a
             # measurement.  No throughput is reported and the process fails.

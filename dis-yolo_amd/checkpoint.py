@@ -323,7 +323,9 @@ def save_checkpoint(prefix: str, tensors: Dict[str, np.ndarray], update_state_fi
     offset = 0
     with open(prefix + ".data-00000-of-00001.tmp", "wb") as f:
         for name in names:
-            a = np.ascontiguousarray(np.asarray(tensors[name]))
+            a = np.asarray(tensors[name])
+            if not a.flags.c_contiguous:
+                a = np.ascontiguousarray(a)           # (np.ascontiguousarray would turn a 0-d variable into shape [1])
             if a.dtype not in _DT_OF:
                 raise TypeError("variable %s has unsupported dtype %s" % (name, a.dtype))
             raw = a.astype(a.dtype.newbyteorder("<"), copy=False).tobytes()

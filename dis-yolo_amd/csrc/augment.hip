@@ -182,8 +182,9 @@ __global__ __launch_bounds__(256) void change_light_kernel(unsigned char* img, i
 }
 
 // linearmotion_blur3C (:466-494) with lineLength 3: a 3x3 line kernel through the centre (angle 0 / 45 / 90 / 135,
-// "full" = three taps, "right" / "left" = the centre and one neighbour), normalised, zero outside the image
-// (scipy.signal.convolve2d(mode='same', fill 0) as pyblur uses it), result truncated to uint8
+// "full" = three taps, "right" / "left" = the centre and one neighbour), normalised; pixels outside the image count as
+// 255 (pyblur's LinearMotionBlur: scipy.signal.convolve2d(img, kernel, mode='same', fillvalue=255.0)), result truncated
+// to uint8
 __global__ __launch_bounds__(256) void motion_blur3_kernel(const unsigned char* src, unsigned char* dst, int S, int dyA, int dxA,
                                                            int use_a, int use_b) {
   const int64_t total = (int64_t)S * S;
@@ -192,15 +193,14 @@ __global__ __launch_bounds__(256) void motion_blur3_kernel(const unsigned char* 
     const int y = (int)(i / S), x = (int)(i - (int64_t)y * S);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      float acc = (float)src[i * 3 + c] * wgt;
-      if (use_a) {
-        const int yy = y + dyA, xx = x + dxA;
-        if (yy >= 0 && yy < S && xx >= 0 && xx < S) acc += (float)src[((size_t)yy * S + xx) * 3 + c] * wgt;
-      }
-      if (use_b) {
-        const int yy = y - dyA, xx = x - dxA;
-        if (yy >= 0 && yy < S && xx >= 0 && xx < S) acc += (float)src[((size_t)yy * S + xx) * 3 + c] * wgt;
-      }
+      // taps in the (flipped) kernel's row-major order: the "b" end first when it lies above / left of the centre
+      float acc = 0.f;
+      const int ya = y + dyA, xa = x + dxA, yb = y - dyA, xb = x - dxA;
+      const float va = (ya >= 0 && ya < S && xa >= 0 && xa < S) ? (float)src[((size_t)ya * S + xa) * 3 + c] : 255.f;
+      const float vb = (yb >= 0 && yb < S && xb >= 0 && xb < S) ? (float)src[((size_t)yb * S + xb) * 3 + c] : 255.f;
+      if (use_a) acc += va * wgt;
+      acc += (float)src[i * 3 + c] * wgt;
+      if (use_b) acc += vb * wgt;
       dst[i * 3 + c] = (unsigned char)min(max((int)acc, 0), 255);
     }
   }
@@ -268,9 +268,14 @@ extern "C" int disyolo_aug_motion_blur3(const uint8_t* src, uint8_t* dst, int si
   DY_REQUIRE(src && dst && src != dst && size > 0 && (angle == 0 || angle == 45 || angle == 90 || angle == 135) && line_type >= 0 && line_type <= 2,
              "aug_motion_blur3: bad args (angle 0/45/90/135, line_type 0 full / 1 right / 2 left)");
   DY_RECORD_OR_RUN([=](void* s) { return disyolo_aug_motion_blur3(src, dst, size, angle, line_type, s); });
-  // direction of the "right" half of the line in image coordinates (y down): 0: +x, 45: up-right, 90: up, 135: up-left
-  const int dxA = angle == 0 ? 1 : (angle == 45 ? 1 : (angle == 90 ? 0 : -1));
-  const int dyA = angle == 0 ? 0 : -1;
+  // the "right" end of the 3x3 line in kernel coordinates (row down): pyblur's LineDictionary anchors
+  // {0: [1,0,1,2], 45: [2,0,0,2], 90: [0,1,2,1], 135: [0,0,2,2]} = (row0, col0, row1, col1); 'right' keeps the SECOND
+  // anchor (the first is replaced by the centre), 'left' the first: 0: +x, 45: up-right, 90: DOWN, 135: DOWN-right.
+  // (Restated from pyblur 0.2.x, which is not installable here: unpinned.  pyblur also mutates the shared anchor list in
+  // place, so after one 'right' and one 'left' call an angle degenerates to the identity for the rest of the process: not
+  // reproduced.)
+  const int dxA = angle == 0 ? 1 : (angle == 45 ? 1 : (angle == 90 ? 0 : 1));
+  const int dyA = angle == 0 ? 0 : (angle == 45 ? -1 : 1);
   const int use_a = line_type != 2, use_b = line_type != 1;
   // a convolution flips the kernel: the tap at kernel offset (+dy,+dx) reads the pixel at (-dy,-dx)
   hipLaunchKernelGGL(motion_blur3_kernel, dim3(grid_for((int64_t)size * size)), dim3(256), 0, (hipStream_t)stream, src, dst, size, -dyA,

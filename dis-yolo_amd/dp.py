@@ -96,6 +96,10 @@ class GradientAllReduce:
                     pad = -(-c // self.world_size) * self.world_size
                     self._stage[key] = torch.zeros(pad, dtype=dt, device=net.grad_arena.device)
         self._pending = []     # (key, offset, count) to copy back after the exchange
+        # trace (set to a list): finish() brackets every wait with events on the compute stream -- the time the
+        # optimizer's stream sits behind each bucket's collective ("exposed wait"; 0 when the exchange hid behind
+        # the backward pass).  bench.py --gpus N reports it so that a first multi-GPU run explains itself.
+        self.trace = None
 
     def begin_step(self) -> None:
         self.works = []
@@ -144,12 +148,34 @@ class GradientAllReduce:
         o, c = self.tail
         if c > 0:
             self._exchange("tail", o, c)
-        for w in self.works:
-            w.wait()
+        if self.trace is not None:
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(self.works) + 1)]
+            evs[0].record()
+            for i, w in enumerate(self.works):
+                w.wait()
+                evs[i + 1].record()
+            self.trace.append(evs)
+        else:
+            for w in self.works:
+                w.wait()
         for key, o, c in self._pending:                   # wire dtype -> the f32 arena
             self.net.grad_arena[o:o + c].copy_(self._stage[key][:c])
         self.works = []
         self._pending = []
+
+
+    def trace_summary(self):
+        """mean exposed wait per collective in microseconds, in the order finish() waits for them (the buckets in
+        firing order, the gamma/beta tail last); call after a device synchronize"""
+        if not self.trace:
+            return None
+        n = min(len(e) for e in self.trace) - 1
+        out = []
+        for i in range(n):
+            out.append(round(sum(e[i].elapsed_time(e[i + 1]) for e in self.trace) / len(self.trace) * 1e3, 1))
+        sizes = [c * 4 / 1e6 for _, _, c in self.buckets] + [self.tail[1] * 4 / 1e6]
+        return {"exposed_wait_us": out, "bucket_mb": [round(x, 2) for x in sizes[:n]], "steps": len(self.trace),
+                "wire": self.wire, "algo": self.algo}
 
 
 def broadcast_parameters(net, src: int = 0, process_group=None) -> None:

@@ -89,16 +89,24 @@ def regions_from_masks(masks: Dict[str, Optional[np.ndarray]]) -> Tuple[Dict[str
     return regions, errors
 
 
-def merge_regions(regions: Dict[str, Dict], object_merge: Sequence[Sequence[float]]) -> Dict[str, Dict]:
+def merge_regions(regions: Dict[str, Dict], object_merge: Sequence[Sequence[float]], state: Optional[Dict] = None,
+                  log=None) -> Dict[str, Dict]:
     """pre_process.py:165-222: the instances whose outer contour's centroid lies inside a 'merge' box of the XML
-    annotation become one instance per box (closest box centre; class crack > rebar > spall).  Behaviour of the
-    reference kept, including that the closest-box index survives from the previous instance when no box
-    contains a centroid (the final containment test then decides)."""
+    annotation become one instance per box (closest box centre; class crack > rebar > spall).
+
+    ``dis_index`` (the closest-box index) is a FUNCTION-level local of the reference's load_verify_contour: it survives
+    from instance to instance AND from image to image (``state`` carries it; load_verify_contour passes one dict for
+    the whole run), and the final containment test decides whether the stale box is used.  Two cases crash the
+    reference (UnboundLocalError when no instance of any image so far had its centroid in a box; IndexError when the
+    stale index does not exist in this image's box list): here the reference's own message for an unassigned
+    instance is logged and the instance is skipped -- a data set the reference pre-processes is never aborted, and
+    gives the same regions."""
     if not object_merge:
         return {}
+    if state is None:
+        state = {}
     groups = {jj: [] for jj in range(len(object_merge))}
     names = {jj: [] for jj in range(len(object_merge))}
-    dis_index = None
     for k in range(len(regions)):
         reg = regions[str(k)]
         poly = reg["shape_attributes"][0]
@@ -109,13 +117,17 @@ def merge_regions(regions: Dict[str, Dict], object_merge: Sequence[Sequence[floa
                 continue
             d = (((x1 + x2) / 2 - cX) ** 2 + ((y1 + y2) / 2 - cY) ** 2) ** 0.5
             if d < old:
-                dis_index, old = ii, d
-        if dis_index is None:
-            raise UnboundLocalError("local variable 'dis_index' referenced before assignment")
-        x1, y1, x2, y2 = object_merge[dis_index]
-        if x1 <= cX <= x2 and y1 <= cY <= y2:
-            groups[dis_index].extend(reg["shape_attributes"])
-            names[dis_index].append(reg["region_attributes"])
+                state["dis_index"], old = ii, d
+        dis_index = state.get("dis_index")
+        assigned = False
+        if dis_index is not None and dis_index < len(object_merge):
+            x1, y1, x2, y2 = object_merge[dis_index]
+            if x1 <= cX <= x2 and y1 <= cY <= y2:
+                groups[dis_index].extend(reg["shape_attributes"])
+                names[dis_index].append(reg["region_attributes"])
+                assigned = True
+        if not assigned and log is not None:
+            log("No merged box belongs to the defect")
     new_regions, count = {}, 0
     for jj in range(len(object_merge)):
         if not groups[jj]:
@@ -155,6 +167,7 @@ def load_verify_contour(data_path: str, phase: str = "train", log=print) -> List
             return pickle.load(f)
     os.makedirs(cache_dir, exist_ok=True)
     annotations, error_mask = [], 0
+    merge_state: Dict = {}        # the reference's function-level dis_index (pre_process.py:192): survives from image to image
     with open(os.path.join(cache_dir, phase + ".txt"), "w") as ids:
         for file in os.listdir(os.path.join(root, "images")):
             name = os.path.splitext(file)[0]
@@ -170,7 +183,7 @@ def load_verify_contour(data_path: str, phase: str = "train", log=print) -> List
             regions, errors = regions_from_masks(masks)
             error_mask += errors
             if has_xml:
-                regions = merge_regions(regions, merge)
+                regions = merge_regions(regions, merge, merge_state, lambda m: log(m + " in " + file))
             with Image.open(os.path.join(root, "images", name + ".jpg")) as im:
                 width, height = im.size
             annotations.append({"filename": file, "regions": regions, "size": [height, width]})

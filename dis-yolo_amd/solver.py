@@ -101,6 +101,11 @@ class Solver(object):
         # tf.random_shuffle of the mask-loss RoIs every step (yolo/yolo3_net_pos.py:781-782): on the device, seeded
         # (a net that already has a seed -- or injected permutations with shuffle_seed=None -- keeps it)
         if net.shuffle_seed is None and shuffle_seed is not None:
+            if getattr(net, "_prog", None) is not None:
+                # the recorded step was built without the device-side shuffle: setting the seed now would change nothing
+                # and the RoI order would stay fixed for the whole run
+                raise ValueError("Solver: the net's step was recorded (build_program) before a shuffle seed was set; set "
+                                 "net.shuffle_seed before build_program(), or pass shuffle_seed=None to keep a fixed RoI order")
             net.shuffle_seed = shuffle_seed
         self.events = open(os.path.join(self.ckpt_dir, "events.jsonl"), "a")
         self.log("*** Train variables ***")

@@ -1093,27 +1093,44 @@ def change_light(image: np.ndarray, coeff: float) -> np.ndarray:
     return np.stack([sat8(ro * f32(255)), sat8(go * f32(255)), sat8(bo * f32(255))], axis=-1)
 
 
-def motion_blur3(img: np.ndarray, angle: int, line_type: int) -> np.ndarray:
-    """linearmotion_blur3C with lineLength 3 (utils/train_data.py:466-494; pyblur.LinearMotionBlur is not
-    installed: unpinned): 3x3 line kernel through the centre at 0/45/90/135 degrees, 'full' (0) three taps,
-    'right' (1) / 'left' (2) the centre and one neighbour, normalised; convolution with zero fill; uint8 truncation"""
-    dxa = {0: 1, 45: 1, 90: 0, 135: -1}[angle]
-    dya = 0 if angle == 0 else -1
+PYBLUR_LINES3 = {0: (1, 0, 1, 2), 45: (2, 0, 0, 2), 90: (0, 1, 2, 1), 135: (0, 0, 2, 2)}
+
+
+def pyblur_line_kernel3(angle: int, line_type: int) -> np.ndarray:
+    """pyblur.LineKernel(3, angle, linetype) (utils/train_data.py:466-494 calls pyblur.LinearMotionBlur; pyblur is not
+    installable here, restated from its 0.2.x source: unpinned).  LineDictionary anchors (row0, col0, row1, col1) per
+    angle; 'right' (1) replaces the first anchor by the centre, 'left' (2) the second; the line between the anchors
+    (skimage.draw.line: for three pixels the two ends and their midpoint) is set to 1 and normalised.  pyblur mutates the
+    shared anchor list in place (after one 'right' and one 'left' call an angle is the identity for the rest of the
+    process): deliberately not reproduced."""
+    r0, c0, r1, c1 = PYBLUR_LINES3[angle]
+    if line_type == 1:
+        r0 = c0 = 1
+    if line_type == 2:
+        r1 = c1 = 1
     k = np.zeros((3, 3), np.float32)
-    k[1, 1] = 1
-    if line_type != 2:
-        k[1 + dya, 1 + dxa] = 1
-    if line_type != 1:
-        k[1 - dya, 1 - dxa] = 1
-    w = np.float32(1.0) / np.float32(k.sum())
+    k[r0, c0] = 1
+    k[r1, c1] = 1
+    if max(abs(r1 - r0), abs(c1 - c0)) == 2:          # a three-pixel line: its midpoint is the centre
+        k[(r0 + r1) // 2, (c0 + c1) // 2] = 1
+    return k / np.float32(np.count_nonzero(k))
+
+
+def motion_blur3(img: np.ndarray, angle: int, line_type: int) -> np.ndarray:
+    """linearmotion_blur3C with lineLength 3 (utils/train_data.py:466-494) = per channel
+    scipy.signal.convolve2d(img.astype(float32), LineKernel, mode='same', fillvalue=255.0).astype(uint8)
+    (pyblur.LinearMotionBlur; tests/test_train_data.py checks this restatement against scipy itself)"""
+    k = pyblur_line_kernel3(angle, line_type)
     S = img.shape[0]
-    pad = np.zeros((S + 2, S + 2, 3), np.float32)
+    pad = np.full((S + 2, S + 2, 3), 255.0, np.float32)
     pad[1:-1, 1:-1] = img.astype(np.float32)
-    out = img.astype(np.float32) * w
-    # convolution: out[y,x] += k[1+dy,1+dx] * in[y-dy, x-dx], taps added in the kernel's order (a then b)
-    for use, (dy, dx) in ((line_type != 2, (dya, dxa)), (line_type != 1, (-dya, -dxa))):
-        if use:
-            out = out + pad[1 - dy:1 - dy + S, 1 - dx:1 - dx + S] * w
+    out = np.zeros(img.shape, np.float32)
+    # convolution: out[y,x] = sum k[i,j] * in[y-(i-1), x-(j-1)], kernel entries in row-major order
+    for i in range(3):
+        for j in range(3):
+            if k[i, j] != 0:
+                dy, dx = i - 1, j - 1
+                out = out + pad[1 - dy:1 - dy + S, 1 - dx:1 - dx + S] * k[i, j]
     return np.clip(out.astype(np.int64), 0, 255).astype(np.uint8)
 
 

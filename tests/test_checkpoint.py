@@ -92,8 +92,15 @@ def test_prefix_compression_restarts_and_multiple_blocks(tmp_path):
     items = ck.parse_table(raw)
     assert [k for k, _ in items] == sorted([b""] + [n.encode() for n in tensors])
     assert len(raw) < sum(len(n) + 40 for n in tensors) * 0.8            # the shared prefixes were not stored
+    # a scalar (global_step-like) and an empty variable keep their shapes: [] and [0], not [1]
+    tensors["global_step"] = np.array(7, np.int64)
+    tensors["yolo/empty"] = np.zeros((0,), np.float32)
+    tensors["yolo/strided"] = np.arange(12, dtype=np.float32).reshape(3, 4).T       # non-contiguous input
+    ck.save_checkpoint(prefix, tensors)
     got = ck.load_checkpoint(prefix)
     assert all(np.array_equal(got[n], tensors[n]) for n in tensors)
+    assert got["global_step"].shape == () and int(got["global_step"]) == 7 and got["yolo/empty"].shape == (0,)
+    assert ck.list_variables(prefix)["global_step"] == ((), ck.DT_INT64) and got["yolo/strided"].shape == (4, 3)
     # corruption is detected: one flipped data byte, one flipped index byte
     d = bytearray(open(prefix + ".data-00000-of-00001", "rb").read())
     d[100] ^= 1

@@ -55,12 +55,19 @@ def _worker(rank, world, port, out, stage, sync_bn=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # loopback: no resolution of the container's hostname
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
-    dev = torch.device("cuda:0")
+    if os.environ.get("DP2_BACKEND") == "nccl":
+        # the production transport: one rank per device over RCCL (needs two GPUs)
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=180))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+        dev = torch.device("cuda:0")
     net = _make_net(stage, 10 + rank, dev)            # different initialisation per rank
     _seed_heads(net, 50 + rank)
     w_init = net.arena.clone()
-    enable_data_parallel(net, bucket_mb=4.0, sync_bn=sync_bn)          # broadcasts rank 0's variables
+    enable_data_parallel(net, bucket_mb=4.0, sync_bn=sync_bn,
+                         algo=os.environ.get("DP2_ALGO") or None)          # broadcasts rank 0's variables
     gathered = [torch.zeros_like(net.arena) for _ in range(world)]
     dist.all_gather(gathered, net.arena)
     flag = torch.tensor([float((w_init != net.arena).any())], device=dev)
@@ -106,6 +113,7 @@ def _worker(rank, world, port, out, stage, sync_bn=False):
         res["state0"] = {k: v.cpu() for k, v in state0.items()}
         torch.save(res, out)
     dist.barrier()
+    torch.cuda.synchronize()
     dist.destroy_process_group()
 
 
@@ -150,6 +158,42 @@ def test_two_ranks_on_one_gpu_over_gloo(dev, tmp_path, stage):
     assert res["buckets"] >= (3 if stage == 2 else 2)
     assert res["ranks_agree"]
     # single-process reproduction of step 1: local gradients of both ranks' batches from the broadcast state
+    grads = []
+    for rank in range(2):
+        n = _make_net(stage, 0, dev)
+        n.load_state_dict({k: v.to(dev) for k, v in res["state0"].items()})
+        n.set_batch(O.synthetic_batch(B, S, seed=100 * (rank + 1)))
+        n.compute_losses(0.1)
+        n.backward()
+        torch.cuda.synchronize()
+        grads.append(n.grad_arena.clone())
+    n.grad_arena.copy_(grads[0] + grads[1])
+    n.optimizer_step(0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(n.arena.cpu(), res["arena_step1"]), \
+        "max |dw| %.3g" % float((n.arena.cpu() - res["arena_step1"]).abs().max())
+
+
+@pytest.mark.parametrize("stage,algo", [(1, "allreduce"), (2, "allreduce"), (1, "rs_ag")])
+def test_two_ranks_on_two_gpus_over_rccl(dev, tmp_path, stage, algo):
+    """The same protocol over the PRODUCTION transport: one rank per device, RCCL (all-reduce, and the
+    reduce-scatter + all-gather variant).  Needs two GPUs -- a one-GPU test box skips it; the first multi-GPU box
+    that runs the suite checks the real thing: rank 0's broadcast, bit-identity of step 1 with the single-process
+    sum of the two local gradients (a two-term f32 sum is order-independent, and so is RCCL's), ranks in lockstep."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    import disyolo_oracle as O
+    out = str(tmp_path / "dp2rccl.pt")
+    os.environ["DP2_BACKEND"] = "nccl"
+    os.environ["DP2_ALGO"] = algo
+    try:
+        _run_ranks((_free_port(), out, stage))
+    finally:
+        os.environ.pop("DP2_BACKEND")
+        os.environ.pop("DP2_ALGO")
+    res = torch.load(out)
+    assert res["bcast_equal"] and res["differed"] == [False, True] and res["finite"]
+    assert res["ranks_agree"]
     grads = []
     for rank in range(2):
         n = _make_net(stage, 0, dev)

@@ -125,8 +125,18 @@ def test_centroid_and_regions_follow_the_oracle():
     assert merged == O.merge_regions(want, boxes) and 1 <= len(merged) <= 3
     assert sum(len(r["shape_attributes"]) for r in merged.values()) == sum(len(r["shape_attributes"]) for r in got.values())
     assert P.merge_regions(got, []) == {}
-    with pytest.raises(UnboundLocalError):                     # the reference's own failure mode: first centroid in no box
-        P.merge_regions(got, [[70.0, 50.0, 75.0, 55.0]])
+    # first centroid in no box: the reference crashes (UnboundLocalError); here its message is logged and the instance skipped
+    msgs = []
+    assert P.merge_regions(got, [[70.0, 50.0, 75.0, 55.0]], {}, msgs.append) == {} and len(msgs) == len(got)
+    # the closest-box index is function-level state of the reference: it survives from image to image, and the final
+    # containment test decides whether the stale box takes the instance
+    state = {}
+    first = P.merge_regions(got, boxes, state)
+    assert first == merged and state["dis_index"] is not None
+    stale = state["dis_index"]
+    far = [[500.0, 500.0, 510.0, 510.0]] * (stale + 1)          # no centroid in any of these boxes
+    assert P.merge_regions(got, far, state) == {} and state["dis_index"] == stale
+    assert P.merge_regions(got, far[:1], {"dis_index": 7}) == {}        # stale index beyond this image's box list
 
 
 def test_load_verify_contour_builds_the_cache(tmp_path):

@@ -50,3 +50,28 @@ def test_resize_u8_identity_and_place_mask_rounding():
     # 2x upscaling of a step edge: values 0, .25, .75, 1 across the edge -> np.around -> 0, 0, 1, 1
     assert out[0].tolist() == [False, False, False, False, True, True, True, True]
     assert np.array_equal(O.place_mask(m, 8, 8, 8, 0, 0, 2), out[:, ::-1])
+
+
+def test_motion_blur_restatement_equals_scipy_convolve2d():
+    """pyblur.LinearMotionBlur (utils/train_data.py:490) is scipy.signal.convolve2d(img, LineKernel, mode='same',
+    fillvalue=255.0).astype(uint8): scipy is importable here, so the oracle's arithmetic (tap order, f32 rounding, uint8
+    truncation, the 255 border) is pinned against it; the kernel table itself is restated from pyblur (not installable)."""
+    from scipy.signal import convolve2d
+    rng = np.random.RandomState(5)
+    img = rng.randint(0, 256, (61, 61, 3)).astype(np.uint8)
+    for angle in (0, 45, 90, 135):
+        for lt in (0, 1, 2):
+            k = O.pyblur_line_kernel3(angle, lt)
+            assert np.count_nonzero(k) == (3 if lt == 0 else 2) and k[1, 1] > 0 and abs(float(k.sum()) - 1) < 1e-6
+            want = np.stack([convolve2d(img[:, :, c].astype(np.float32), k, mode="same", fillvalue=255.0).astype("uint8")
+                             for c in range(3)], -1)
+            np.testing.assert_array_equal(O.motion_blur3(img, angle, lt), want, err_msg="%d %d" % (angle, lt))
+    # the conventions of pyblur's LineDictionary: 'right' keeps the SECOND anchor -- for 90 degrees that is the row
+    # BELOW the centre, for 135 degrees the pixel below-right; a convolution reads the mirrored neighbour
+    assert O.pyblur_line_kernel3(90, 1)[2, 1] > 0 and O.pyblur_line_kernel3(135, 1)[2, 2] > 0
+    assert O.pyblur_line_kernel3(45, 1)[0, 2] > 0 and O.pyblur_line_kernel3(0, 2)[1, 0] > 0
+    one = np.zeros((5, 5, 3), np.uint8)
+    one[2, 2] = 90
+    out = O.motion_blur3(one, 90, 1).astype(int)[:, :, 0]
+    assert out[2, 2] == 45 and out[3, 2] == 45 and out[1, 2] == 0        # the impulse spreads DOWN
+    assert out[0, 0] == 127                                              # border: (0 + 255) / 2
