@@ -7,6 +7,9 @@ independent restatement on random images, (iii) topological invariants computed 
 import os
 import pickle
 
+import json
+import os
+
 import numpy as np
 import pytest
 from scipy import ndimage
@@ -165,3 +168,46 @@ def test_load_verify_contour_builds_the_cache(tmp_path):
         assert pickle.load(f) == ann
     assert (root / "cache" / "train.txt").read_text() == "a\n"
     assert P.load_verify_contour(str(tmp_path / "data"), "train", log=lambda s: None) == ann      # second call: from the cache
+
+
+def test_reference_sample_data_golden_and_synthetic_replay():
+    """tests/golden/pre_process_sample.json = load_verify_contour run on the reference's own data/train_sample (four
+    images, six class masks, 00044.xml with four 'merge' boxes; tools/make_golden_pre_process.py, build container
+    only -- the JPEGs do not travel).  (1) what the file records must be self-consistent: the contour tracer's outer
+    borders / holes equal scipy.ndimage's independent component counts of the same masks, and the four merge boxes
+    of 00044.xml became four merged instances (three rebar pieces in the first box).  (2) replay: synthetic masks
+    with one small blob at every recorded instance centroid go through regions_from_masks + merge_regions with the
+    recorded boxes and must reproduce the merged instances (class, number of polygons, box)."""
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pre_process_sample.json")))
+    assert [im["filename"] for im in g["images"]] == ["00044.jpg", "00054.jpg", "001005.jpg", "01015.jpg"]
+    for im in g["images"]:
+        before = im["instances_before_merge"]
+        for cls, ind in im["independent"].items():
+            mine = [b for b in before if b["class"] == cls]
+            assert len(mine) == ind["components_8"], (im["filename"], cls)          # outer borders <-> 8-connected components
+            assert sum(b["holes"] for b in mine) == ind["holes"]
+        assert im["mask_errors"] == 0
+        H, W = im["size_hw"]
+        for inst in im["instances"]:
+            x1, y1, x2, y2 = inst["bbox"]
+            assert 0 <= x1 <= x2 < W and 0 <= y1 <= y2 < H
+    im44 = g["images"][0]
+    assert len(im44["merge_boxes"]) == 4 and len(im44["instances_before_merge"]) == 6
+    assert [(i["class"], i["polygons"]) for i in im44["instances"]] == [("rebar", 3), ("spall", 1), ("rebar", 1), ("rebar", 1)]
+    assert [len(im["instances"]) for im in g["images"][1:]] == [2, 2, 1]           # no XML: instances pass through
+    # ---- replay on synthetic masks of the same topology
+    state = {}
+    for im in g["images"]:
+        H, W = im["size_hw"]
+        masks = {c: None for c in ("crack", "spall", "rebar")}
+        for b in im["instances_before_merge"]:
+            if masks[b["class"]] is None:
+                masks[b["class"]] = np.zeros((H, W), np.uint8)
+            cx, cy = b["centroid"]
+            masks[b["class"]][max(cy - 3, 0):cy + 4, max(cx - 3, 0):cx + 4] = 255
+        regions, errors = P.regions_from_masks(masks)
+        assert errors == 0 and len(regions) == len(im["instances_before_merge"])
+        if im["merge_boxes"] is not None:
+            regions = P.merge_regions(regions, im["merge_boxes"], state)
+        assert [(r["region_attributes"], len(r["shape_attributes"])) for r in (regions[str(k)] for k in range(len(regions)))] == \
+            [(i["class"], i["polygons"]) for i in im["instances"]], im["filename"]
