@@ -202,12 +202,12 @@ def secondary_measurements(args, dev):
     import subprocess
     out = {}
     S = args.size
-    common = ["--size", str(S), "--steps", "10", "--warmup", "3", "--repeats", "5", "--autotune", args.autotune,
+    common = ["--steps", "10", "--warmup", "3", "--repeats", "5", "--autotune", args.autotune,
               "--tune-cache", args.tune_cache, "--no-secondary", "--no-cpu-baseline", "--no-kernel-events"]
 
-    def child(extra):
-        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra + common, stdout=subprocess.PIPE,
-                           stderr=subprocess.DEVNULL, timeout=600)
+    def child(extra, size=S):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra + ["--size", str(size)] + common,
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
         lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
         if lines and json.loads(lines[-1]).get("error"):
             raise RuntimeError(json.loads(lines[-1])["error"])       # e.g. a non-finite loss: no throughput is taken from it
@@ -226,6 +226,19 @@ def secondary_measurements(args, dev):
                                "conv_tiles": d["config"].get("conv_tiles"), "process": "child"}
     except Exception as e:   # a secondary line must never cost the headline
         out["train_stage2"] = {"error": repr(e)[:200]}
+    # BASELINE.json configs[4] at its per-GPU size: 832x832, 4 images per GPU, stage 1, the locked backbone in OCP e4m3
+    # (and the same step in bf16 beside it: the non-scaled fp8 MFMA runs at the bf16 rate, fp8 can only win on bytes)
+    for key, dt in (("train_832_fp8", "fp8"), ("train_832_bf16", "bf16")):
+        try:
+            d = child(["--stage", "1", "--batch", "4", "--dtype", dt], size=832)
+            gf = TRAIN_GFLOP_PER_IMG_576[1] * (832 / 576.0) ** 2
+            out[key] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
+                        "ms_per_step": d["ms_per_step"], "steps": d["steps"], "repeats": d.get("repeats"), "dtype": d["dtype"],
+                        "frac_of_mfma_peak": round(gf * d["value"] / 1e3 / MFMA_PEAK_TFLOPS, 4),
+                        "loss_first": d["config"].get("loss_first"), "loss_last": d["config"].get("loss_last"),
+                        "conv_tiles": d["config"].get("conv_tiles"), "process": "child"}
+        except Exception as e:
+            out[key] = {"error": repr(e)[:200]}
     try:
         d = child(["--task", "infer", "--batch", "32"])
         out["infer_b32_graph"] = {"workload": d["config"]["workload"] + "_hipgraph (network + NMS + PS-RoI mask assembly)",

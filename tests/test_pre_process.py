@@ -4,11 +4,9 @@ border following is held to (i) hand-derived answers that follow from the docume
 cv2.findContours (outer borders from their top-left pixel down the left side, holes the other way round, every
 border pixel visit listed, siblings newest first, [next, previous, first_child, parent]), (ii) the oracle's
 independent restatement on random images, (iii) topological invariants computed with scipy.ndimage."""
-import os
-import pickle
-
 import json
 import os
+import pickle
 
 import numpy as np
 import pytest
