@@ -755,8 +755,10 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
   // multiplied one M fragment at a time, inside a wave-uniform branch per fragment: every 4 MFMAs paid a full LDS
   // latency and the scheduler could not move anything across the branches -- MFMA pipe 25-28 % busy.)  The slice body
   // is branch-free: a wave that owns fewer than FW fragments multiplies a dummy one (pixel 0 of the patch, never
-  // stored; the block is as slow as its fullest wave anyway), and the DMAs issued during the LAST slice get an
-  // out-of-range scalar offset -- no memory traffic, zeros into the stage nobody reads again -- instead of a branch.
+  // stored; the block is as slow as its fullest wave anyway), and the last slice -- which has no successor to
+  // prefetch -- is a second copy of the body without the DMAs instead of a branch around each of them.  A layer with
+  // 32 input channels has ONE slice: it never touches the second stage, the launcher then allocates one stage only
+  // and more blocks share a CU (their prologues and epilogues overlap).
   bf16x8 wfr[2][NI], xfr[2][FW];
   auto load_frags = [&]<int TAP>(std::integral_constant<int, TAP>, const char* st) {
     constexpr int kh = TAP / 3, kw = TAP % 3, bi = TAP & 1;
@@ -768,11 +770,11 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
       xfr[bi][t] = *reinterpret_cast<const bf16x8*>(st + hp * 64 + swz_any(hp, fchunk) * 16);
     }
   };
-  for (int c = 0; c < nch; ++c) {
+  auto slice_body = [&]<bool DMA>(std::bool_constant<DMA>, int c) {
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // slice c has landed for everyone; everyone is done with slice c-1
     asm volatile("" ::: "memory");
-    const unsigned cs_next = (c + 1 < nch) ? (unsigned)(c + 1) * 64u : OOB;
+    const unsigned cs_next = (unsigned)(c + 1) * 64u;
     const int stage_next = (c + 1) & 1;
     const char* st = smem + (c & 1) * STB;
     load_frags(std::integral_constant<int, 0>{}, st);
@@ -780,9 +782,11 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
       constexpr int bi = TAP & 1;
       if constexpr (TAP < 8) load_frags(std::integral_constant<int, TAP + 1>{}, st);
       __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise sinks the reads back next to their uses)
-      [&]<int... D>(std::integer_sequence<int, D...>) {
-        (issue_one(std::integral_constant<int, TAP * DPT + D>{}, cs_next, stage_next), ...);
-      }(std::make_integer_sequence<int, DPT>{});
+      if constexpr (DMA) {
+        [&]<int... D>(std::integer_sequence<int, D...>) {
+          (issue_one(std::integral_constant<int, TAP * DPT + D>{}, cs_next, stage_next), ...);
+        }(std::make_integer_sequence<int, DPT>{});
+      }
 #pragma unroll
       for (int t = 0; t < FW; ++t)
 #pragma unroll
@@ -799,8 +803,9 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
     [&]<int... T>(std::integer_sequence<int, T...>) {
       (tap_body(std::integral_constant<int, T>{}), ...);
     }(std::make_integer_sequence<int, 9>{});
-  }
-  wait_vmcnt<0>();   // the zero-fill DMAs of the last slice: the epilogue reuses the stages
+  };
+  for (int c = 0; c + 1 < nch; ++c) slice_body(std::bool_constant<true>{}, c);
+  slice_body(std::bool_constant<false>{}, nch - 1);
   __syncthreads();
 
   // ---- epilogue.  acc[t][j][r]: patch pixel q_of[t] (lane & 15), channel n0 + j*16 + 4*(lane>>4) + r
@@ -1067,11 +1072,15 @@ int launch_halo(const ConvParams& p, Patch pt, hipStream_t s) {
   q.tilesM = p.B * tilesY * tilesX;
   q.tilesN = ceil_div(p.Cout, BN);
   constexpr int SLAB = NW * 1024, BIM = (9 * BN * 4 + NW * 64 - 1) / (NW * 64);
-  const size_t lds = (size_t)2 * (4 + BIM) * SLAB;
+  // two stages (compute slice c while slice c+1 lands); a one-slice layer (32 input channels) uses the first only.
+  // The epilogue's scratch (stats rows + per-wave staging tiles) must fit as well.
+  const size_t epi = (size_t)NW * BN * 8 + (size_t)NW * FW * 16 * (BN * 2 + 16);
+  size_t lds = (size_t)(p.Cin > 32 ? 2 : 1) * (4 + BIM) * SLAB;
+  if (lds < epi) lds = epi;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<NW, FW, NI>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * (4 + BIM) * SLAB));
     attr_set = true;
   }
   hipLaunchKernelGGL((conv_halo_kernel<NW, FW, NI>), dim3(q.tilesM * q.tilesN), dim3(NW * 64), lds, s, q, pt.ph,
