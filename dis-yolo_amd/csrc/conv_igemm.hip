@@ -1022,6 +1022,303 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming variant of the patch kernel for 3x3 stride-1 layers with 32 input channels (ONE K slice): the wide, shallow
+// ends of the network (32 -> 64 at 288^2, forward of conv4 / conv81), whose time is memory traffic, not MFMA work.
+//
+// Ablations of the per-patch kernel on that shape (tools/r3_call16.sh, B = 8): 71 us in all; 40 us with the MFMAs AND
+// the epilogue compiled out -- i.e. staging alone (launch, 37 KB of weights and a 30 KB halo per block, one block per
+// CU, 6.75 rounds of blocks) costs 5.9 us per block, the cold-start rate of a CU's memory path (~12 B/clk), against
+// 7 us for reading the whole input once at HBM speed.  Nothing overlaps: load, multiply, store, next block.
+//
+// Here a block is persistent: it loads its 9 x BN x 32 weights ONCE, then walks over patches g, g+G, g+2G ...; the
+// halo of the NEXT patch is in flight (LDS-DMA into the other of two halo stages) while the current one is multiplied
+// and stored.  The stores leave as buffer stores issued from inline asm -- always FW*RPF per wave and patch, lanes
+// outside the tensor get an out-of-range offset and are dropped by the range check -- so the wait at the top of the
+// loop is a COUNTED vmcnt that retires the halo DMAs but leaves the previous patch's stores in flight: store drain,
+// next-halo fetch and the multiply of the current patch overlap.  Per patch a CU moves 30 KB in and 49 KB out
+// (+49 KB residual) for 1.8 us of MFMA work: the kernel is bound by HBM, which is the point.
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buffer_store16(const uint4& v, unsigned voff, i32x4 srd) {
+  i32x4v d;
+  d[0] = (int)v.x; d[1] = (int)v.y; d[2] = (int)v.z; d[3] = (int)v.w;
+  // (s_nop 1: a store of more than 64 bits reads its data registers over two cycles, and hipcc neither knows that this
+  //  statement is one nor pads it -- without the nop its next instruction overwrote the first data register)
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(d), "v"(voff), "s"(srd) : "memory");
+}
+
+template <int NW, int FW, int NI>
+__global__ __launch_bounds__(NW * 64) void conv_stream_kernel(ConvParams p, int PH, int PW, int tilesY, int tilesX, int G) {
+  constexpr int BN = NI * 16;
+  constexpr int SLAB = NW * 1024;
+  constexpr int AIM = 4;                                        // halo DMAs per wave (<= 64*NW pixels)
+  constexpr int BIM = (9 * BN * 4 + NW * 64 - 1) / (NW * 64);   // weight DMAs per wave
+  constexpr int A_BYTES = AIM * SLAB, W_BYTES = BIM * SLAB;
+  constexpr int ROWP = BN * 2 + 16;
+  constexpr int STG = FW * 16 * ROWP;                           // epilogue staging per wave
+  constexpr int CPR8 = BN / 8;                                  // 16-byte chunks per pixel row
+  static_assert(64 % CPR8 == 0, "a lane keeps its chunk column over the write-out rounds");
+  constexpr int RPF = (16 * CPR8 + 63) / 64;
+  constexpr int NST = FW * RPF;                                 // stores per wave and patch (always issued)
+  static_assert(NW * BN * 8 <= STG, "the statistics scratch aliases wave 0's staging tile");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  char* const stg_base = smem + W_BYTES + 2 * A_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt = blockIdx.x % p.tilesN, g = blockIdx.x / p.tilesN;
+  const int n0 = nt * BN;
+  const int tpi = tilesY * tilesX;
+  const int HW_ = PW + 2, NPIX = (PH + 2) * HW_, NOUT = PH * PW;
+
+  const i32x4 srd0 = make_srd(p.x0, p.bytes0);
+  const i32x4 srdw = make_srd(p.w, p.bytesw);
+  const i32x4 srdy = make_srd(p.y, (unsigned)((size_t)p.M * p.Cout * 2));
+
+  // halo gather: which halo pixel / chunk each of this lane's AIM DMAs fills is the same for every patch
+  int hy[AIM], hx[AIM];
+  unsigned hsw[AIM];
+  bool hval[AIM];
+#pragma unroll
+  for (int j = 0; j < AIM; ++j) {
+    const int chunk = (j * NW + wave) * 64 + lane;
+    const int hp = chunk >> 2, pc = chunk & 3;
+    divmod_small(hp < NPIX ? hp : 0, HW_, hy[j], hx[j]);
+    hval[j] = hp < NPIX;
+    hsw[j] = swz_any(hp, pc) * 16;
+  }
+  auto patch_origin = [&](int mt, int& b, int& y0, int& x0) {
+    b = mt / tpi;
+    const int pr = mt - b * tpi;
+    const int ty = pr / tilesX, tx = pr - ty * tilesX;
+    y0 = ty * PH;
+    x0 = tx * PW;
+  };
+  auto issue_halo = [&](int mt, int stage) {
+    int b, y0, x0;
+    patch_origin(mt, b, y0, x0);
+    const unsigned sbase = lds0 + W_BYTES + stage * A_BYTES + wave * 1024;
+    [&]<int... J>(std::integer_sequence<int, J...>) {
+      ((void)[&] {
+        const int iy = y0 + hy[J] - p.pad_t, ix = x0 + hx[J] - p.pad_l;
+        const bool ok = hval[J] && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
+        const unsigned off = ok ? (unsigned)(((b * p.H + iy) * p.W + ix) * p.C0) * 2u + hsw[J] : OOB;
+        dma16<J * SLAB>(off, srd0, 0u, sbase);
+      }(), ...);
+    }(std::make_integer_sequence<int, AIM>{});
+  };
+  {  // the weights of this block's channel tile: once
+    const unsigned sbase = lds0 + wave * 1024;
+    [&]<int... J>(std::integer_sequence<int, J...>) {
+      ((void)[&] {
+        const int chunk = (J * NW + wave) * 64 + lane;
+        const int rb = chunk >> 2, pc = chunk & 3;     // row = tap*BN + n
+        const int tap = rb / BN, nl = rb - tap * BN;
+        const bool ok = (rb < 9 * BN) && (n0 + nl < p.Cout);
+        const unsigned off = ok ? ((unsigned)(n0 + nl) * (unsigned)p.K + (unsigned)(tap * p.Cin)) * 2u + swz_any(rb, pc) * 16 : OOB;
+        dma16<J * SLAB>(off, srdw, 0u, sbase);
+      }(), ...);
+    }(std::make_integer_sequence<int, BIM>{});
+  }
+
+  // fragment read state (patch geometry: the same for every patch)
+  const int frow = lane & 15, fchunk = lane >> 4;
+  int hp0[FW], q_of[FW], py_of[FW], px_of[FW];
+#pragma unroll
+  for (int t = 0; t < FW; ++t) {
+    const int q = (wave + NW * t) * 16 + frow;
+    const bool ok = q < NOUT;
+    divmod_small(ok ? q : 0, PW, py_of[t], px_of[t]);
+    hp0[t] = py_of[t] * HW_ + px_of[t];
+    q_of[t] = ok ? q : -1;
+  }
+  unsigned wb[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int rb = j * 16 + frow;
+    wb[j] = rb * 64 + swz_any(rb, fchunk) * 16;
+  }
+  const int cq = lane >> 4;
+  // fragment byte offsets inside a halo stage per (fragment, tap): patch geometry only, computed once (27 registers
+  // instead of ~4 VALU instructions per fragment read)
+  unsigned xoff[FW][9];
+#pragma unroll
+  for (int t = 0; t < FW; ++t)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int hp = hp0[t] + (tap / 3) * HW_ + (tap % 3);
+      xoff[t][tap] = (unsigned)(hp * 64 + swz_any(hp, fchunk) * 16);
+    }
+  // the epilogue's per-channel scale / shift: parked in LDS behind the staging tiles (BN x 2 floats), read per patch
+  float* const ssc = reinterpret_cast<float*>(stg_base + NW * STG);
+  for (int nl = tid; nl < BN; nl += NW * 64) {
+    const int n = n0 + nl;
+    ssc[nl] = (p.scale && n < p.Cout) ? p.scale[n] : 1.f;
+    ssc[BN + nl] = (p.shift && n < p.Cout) ? p.shift[n] : 0.f;
+  }
+  const bool use_res = p.residual != nullptr;
+
+  int mt = g;
+  issue_halo(mt, 0);
+  for (int it = 0; mt < p.tilesM; ++it, mt += G) {
+    const int cur = it & 1;
+    // In issue order this wave has in flight: [weights, first time] halo(it) | stores(it-1).  Retire the DMAs, leave the
+    // NST stores of the previous patch in flight.
+    if (it == 0)
+      wait_vmcnt<0>();
+    else
+      wait_vmcnt<NST>();
+    __builtin_amdgcn_s_barrier();   // halo(it) has landed for everyone; everyone is done with patch it-1 (halo stage, staging tiles)
+    asm volatile("" ::: "memory");
+    if (mt + G < p.tilesM) issue_halo(mt + G, cur ^ 1);
+    const char* st = smem + W_BYTES + cur * A_BYTES;
+
+    f32x4 acc[FW][NI];
+#pragma unroll
+    for (int t = 0; t < FW; ++t)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 wfr[2][NI], xfr[2][FW];
+    auto load_frags = [&]<int TAP>(std::integral_constant<int, TAP>) {
+      constexpr int bi = TAP & 1;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) wfr[bi][j] = *reinterpret_cast<const bf16x8*>(smem + wb[j] + TAP * BN * 64);
+#pragma unroll
+      for (int t = 0; t < FW; ++t) xfr[bi][t] = *reinterpret_cast<const bf16x8*>(st + xoff[t][TAP]);
+    };
+    // the residual tile (accumulator layout: 4 channels of one pixel per lane and N fragment), requested NOW so that it
+    // lands while the patch is multiplied; clamped addresses instead of a branch per load (hipcc serialises those)
+    int b, y0, x0;
+    patch_origin(mt, b, y0, x0);
+    int m_of[FW];
+#pragma unroll
+    for (int t = 0; t < FW; ++t) m_of[t] = q_of[t] >= 0 ? (b * p.Ho + y0 + py_of[t]) * p.Wo + x0 + px_of[t] : -1;
+    uint2 rres[FW][NI];
+    if (use_res) {
+#pragma unroll
+      for (int t = 0; t < FW; ++t)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int n = n0 + j * 16 + cq * 4;
+          const size_t off = (size_t)(m_of[t] >= 0 ? m_of[t] : 0) * p.Cout + (n < p.Cout ? n : 0);
+          rres[t][j] = *reinterpret_cast<const uint2*>(p.residual + off);
+        }
+    }
+    load_frags(std::integral_constant<int, 0>{});
+    auto tap_body = [&]<int TAP>(std::integral_constant<int, TAP>) {
+      constexpr int bi = TAP & 1;
+      if constexpr (TAP < 8) load_frags(std::integral_constant<int, TAP + 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < FW; ++t)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+#ifdef DY_PROBE
+          if (p.flags & 0x10000) {
+            asm volatile("" ::"v"(xfr[bi][t]), "v"(wfr[bi][j]));
+            continue;
+          }
+#endif
+          acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[bi][j], xfr[bi][t], acc[t][j], 0, 0, 0);
+        }
+    };
+    [&]<int... T>(std::integer_sequence<int, T...>) {
+      (tap_body(std::integral_constant<int, T>{}), ...);
+    }(std::make_integer_sequence<int, 9>{});
+
+    // ---- epilogue of patch mt.  acc[t][j][r]: patch pixel q_of[t], channel n0 + j*16 + 4*cq + r
+    if (p.flags & DISYOLO_CONV_STATS) {
+      float* red = reinterpret_cast<float*>(stg_base);  // [NW][BN][2]
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int t = 0; t < FW; ++t) {
+            const float v = q_of[t] >= 0 ? acc[t][j][r] : 0.f;
+            s1 += v;
+            s2 += v * v;
+          }
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+          }
+          if (frow == 0) {
+            const int nl = j * 16 + cq * 4 + r;
+            red[(wave * BN + nl) * 2 + 0] = s1;
+            red[(wave * BN + nl) * 2 + 1] = s2;
+          }
+        }
+      }
+      __syncthreads();
+      for (int nl = tid; nl < BN; nl += NW * 64) {
+        const int n = n0 + nl;
+        if (n < p.Cout) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int w_ = 0; w_ < NW; ++w_) {
+            s1 += red[(w_ * BN + nl) * 2 + 0];
+            s2 += red[(w_ * BN + nl) * 2 + 1];
+          }
+          p.stats[((size_t)mt * p.Cout + n) * 2 + 0] = s1;
+          p.stats[((size_t)mt * p.Cout + n) * 2 + 1] = s2;
+        }
+      }
+      __syncthreads();   // the scratch is wave 0's staging tile
+    }
+    char* sw = stg_base + wave * STG;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const float4 sc4 = *reinterpret_cast<const float4*>(ssc + j * 16 + cq * 4);
+      const float4 sh4 = *reinterpret_cast<const float4*>(ssc + BN + j * 16 + cq * 4);
+      const float esc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, esh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+#pragma unroll
+      for (int t = 0; t < FW; ++t) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[t][j][r] * esc[r] + esh[r];
+          if (p.flags & DISYOLO_CONV_LEAKY) v[r] = leaky(v[r], p.alpha);
+        }
+        if (use_res) {
+          const uint2 rr = rres[t][j];
+          v[0] += __builtin_bit_cast(float, rr.x << 16);
+          v[1] += __builtin_bit_cast(float, rr.x & 0xffff0000u);
+          v[2] += __builtin_bit_cast(float, rr.y << 16);
+          v[3] += __builtin_bit_cast(float, rr.y & 0xffff0000u);
+        }
+        uint2 o2;
+        o2.x = pack2(v[0], v[1]);
+        o2.y = pack2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(sw + (t * 16 + frow) * ROWP + (j * 16 + cq * 4) * 2) = o2;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int t = 0; t < FW; ++t) {
+#pragma unroll
+      for (int r_ = 0; r_ < RPF; ++r_) {
+        const int idx = r_ * 64 + lane;
+        const int r16 = idx / CPR8, ch = idx % CPR8;
+        const int m = __shfl(m_of[t], r16, 64);     // the pixel of row r16 of this fragment lives in lane r16
+        const int n = n0 + ch * 8;
+        const uint4 o = *reinterpret_cast<const uint4*>(sw + (t * 16 + r16) * ROWP + ch * 16);
+        unsigned off = (m >= 0 && n < p.Cout) ? (unsigned)(((size_t)m * p.Cout + n) * 2) : OOB;
+#ifdef DY_PROBE
+        if (p.flags & 0x80000) off = OOB;      // timing probe: every store dropped by the range check
+#endif
+        buffer_store16(o, off, srdy);
+      }
+    }
+  }
+}
+
 // patch of the halo kernel for an H x W image: PH | H, PW | W, at most max_frags*16 output
 // pixels and max_halo halo pixels; the largest area wins, then the squarest.  0 = none fits.
 struct Patch {
@@ -1064,6 +1361,46 @@ bool halo_ok(const disyolo_conv_desc* d, int id, Patch* out) {
   if (out) *out = pt;
   return true;
 }
+// tile id 20: the streaming kernel (3x3 stride 1, exactly 32 input channels, bf16 output with whole 16-byte channel
+// chunks, no fused batch-norm backward sums)
+bool stream_ok(const disyolo_conv_desc* d, Patch* out) {
+  if (d->ksize != 3 || d->stride != 1 || d->in_div != 1 || d->C1 != 0 || d->C0 != 32) return false;
+  if (d->Ho != d->H || d->Wo != d->W || d->pad_t != 1 || d->pad_l != 1) return false;
+  if ((d->flags & (DISYOLO_CONV_OUT_F32 | DISYOLO_CONV_BN_BWD_STATS)) || d->Cout % 8) return false;
+  if ((int64_t)d->B * d->Ho * d->Wo * d->Cout * 2 >= (1LL << 31)) return false;      // 32-bit store offsets
+  const Patch pt = pick_patch(d->H, d->W, 24, 512);
+  if (pt.ph == 0 || pt.ph * pt.pw < 64) return false;
+  if (out) *out = pt;
+  return true;
+}
+int launch_stream(const ConvParams& p, Patch pt, hipStream_t s) {
+  constexpr int NW = 8, FW = 3, NI = 4, BN = 64;
+  ConvParams q = p;
+  const int tilesY = p.H / pt.ph, tilesX = p.W / pt.pw;
+  q.tilesM = p.B * tilesY * tilesX;
+  q.tilesN = ceil_div(p.Cout, BN);
+  constexpr int SLAB = NW * 1024, BIM = (9 * BN * 4 + NW * 64 - 1) / (NW * 64);
+  const size_t lds = (size_t)BIM * SLAB + 2 * 4 * SLAB + (size_t)NW * FW * 16 * (BN * 2 + 16) + BN * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stream_kernel<NW, FW, NI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  static const int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  int G = ncu / q.tilesN;          // one persistent block per CU (the LDS holds one)
+  if (G < 1) G = 1;
+  if (G > q.tilesM) G = q.tilesM;
+  hipLaunchKernelGGL((conv_stream_kernel<NW, FW, NI>), dim3(G * q.tilesN), dim3(NW * 64), lds, s, q, pt.ph, pt.pw, tilesY,
+                     tilesX, G);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
 template <int NW, int FW, int NI>
 int launch_halo(const ConvParams& p, Patch pt, hipStream_t s) {
   ConvParams q = p;
@@ -1240,7 +1577,7 @@ extern "C" size_t disyolo_conv_desc_size(void) { return sizeof(disyolo_conv_desc
 extern "C" int disyolo_conv2d_bn_bwd_stats_ok(const disyolo_conv_desc* d) {
   if (!d || (d->flags & DISYOLO_CONV_OUT_F32) || d->Cout % 8) return 0;
   const int sel = pick_tile(d, d->B * d->Ho * d->Wo);
-  return (sel & 0xff) >= 16 && halo_ok(d, sel & 0xff, nullptr) ? 1 : 0;
+  return (sel & 0xff) >= 16 && (sel & 0xff) != 20 && halo_ok(d, sel & 0xff, nullptr) ? 1 : 0;
 }
 
 extern "C" int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d) {
@@ -1249,7 +1586,7 @@ extern "C" int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d) {
   int sel = pick_tile(d, M);
   if ((sel & 0xff) >= 16) {
     Patch pt;
-    if (halo_ok(d, sel & 0xff, &pt)) return d->B * (d->H / pt.ph) * (d->W / pt.pw);
+    if ((sel & 0xff) == 20 ? stream_ok(d, &pt) : halo_ok(d, sel & 0xff, &pt)) return d->B * (d->H / pt.ph) * (d->W / pt.pw);
     sel = pick_auto(d, M);
   }
   const int bm = tile_bm(sel & 0xff);
@@ -1271,7 +1608,7 @@ extern "C" int disyolo_conv2d_tile(const disyolo_conv_desc* d, int* bm, int* bn,
   int sel = pick_tile(d, d->B * d->Ho * d->Wo);
   if ((sel & 0xff) >= 16) {
     Patch pt;
-    if (halo_ok(d, sel & 0xff, &pt)) {
+    if ((sel & 0xff) == 20 ? stream_ok(d, &pt) : halo_ok(d, sel & 0xff, &pt)) {
       if (bm) *bm = pt.ph * pt.pw;
       if (bn) *bn = halo_bn(sel & 0xff);
       if (bk) *bk = 32;
@@ -1336,6 +1673,11 @@ extern "C" int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream) {
   // tile field: low byte = tile id (0 = auto); bit 8 forces BK = 32, bit 9 selects the
   // alternative pipeline depth (tuning / testing)
   int sel = pick_tile(d, p.M);
+  if ((sel & 0xff) == 20) {
+    Patch pt;
+    if (stream_ok(d, &pt)) return launch_stream(p, pt, s);
+    sel = pick_auto(d, p.M);   // shape not covered by the streaming kernel
+  }
   if ((sel & 0xff) >= 16) {
     Patch pt;
     if (halo_ok(d, sel & 0xff, &pt))

@@ -76,7 +76,9 @@ typedef struct disyolo_conv_desc {
                              (1-12 GEMM block tiles 64x64 ... 256x128, 13-15 the same
                              with two K groups per block, 16/17 the 3x3 stride-1 patch
                              kernel with 8/4 waves, 18 = 16 with 32 instead of 64 output
-                             channels per block; an id that does not cover the shape
+                             channels per block, 20 = the persistent streaming form of
+                             the patch kernel for 3x3 stride-1 layers with exactly 32
+                             input channels; an id that does not cover the shape
                              falls back), bit 8 = force K depth 32, bit 9 = the tile's
                              alternative pipeline depth                              */
   const void* x0;         /* bf16 [B,H,W,C0]                                          */

@@ -164,6 +164,53 @@ def test_conv_halo_residual_f32_and_pads(dev, tile):
     check(y, before + O.conv2d_same(x, w, 1), 2.0 ** -7, 2e-3)
 
 
+@pytest.mark.parametrize("B,H,W,Cout", [(2, 36, 36, 64), (3, 72, 48, 64), (1, 144, 144, 128), (2, 18, 90, 40)])
+def test_conv_stream_kernel_32_input_channels(dev, B, H, W, Cout):
+    """tile 20, the persistent streaming patch kernel (3x3 stride 1, 32 input channels): folded BN + leaky + residual,
+    the training-mode form (raw output + per-patch statistics rows), an accumulating data gradient, ragged channel
+    tiles (Cout 40), more patches than persistent blocks' first round and fewer -- against the f64 conv"""
+    g = torch.Generator().manual_seed(B * 100 + H + Cout)
+    x = bf16r(torch.randn(B, H, W, 32, generator=g))
+    w = bf16r(torch.randn(3, 3, 32, Cout, generator=g) / 17)
+    res = bf16r(torch.randn(B, H, W, Cout, generator=g))
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.3
+    xd, wd = x.to(torch.bfloat16).to(dev), pack_ref(w).to(torch.bfloat16).to(dev)
+    y = torch.full((B, H, W, Cout), float("nan"), dtype=torch.bfloat16, device=dev)
+    d = L.make_conv_desc(xd, wd, y, 3, 1, scale=scale.to(dev), shift=shift.to(dev), residual=res.to(torch.bfloat16).to(dev),
+                         leaky=True, tile=20)
+    assert L.conv2d_tile(d)[0] == 20
+    L.conv2d_fwd(d)
+    torch.cuda.synchronize()
+    conv = O.conv2d_same(x, w, 1)
+    check(y, O.leaky_relu(conv * scale.double() + shift.double(), 0.1) + res, 2.0 ** -7, 2e-3)
+    # training-mode batch norm: raw output + statistics partials, one row per patch
+    y2 = torch.full((B, H, W, Cout), float("nan"), dtype=torch.bfloat16, device=dev)
+    rows = L.conv2d_stats_rows(L.make_conv_desc(xd, wd, y2, 3, 1, tile=20))
+    stats = torch.full((rows, Cout, 2), float("nan"), dtype=torch.float32, device=dev)
+    L.conv2d_fwd(L.make_conv_desc(xd, wd, y2, 3, 1, stats=stats, tile=20))
+    torch.cuda.synchronize()
+    check(y2, conv, 2.0 ** -7, 1e-3)
+    flat = conv.reshape(-1, Cout)
+    got = stats.double().sum(0).cpu()
+    assert torch.allclose(got[:, 0], flat.sum(0), rtol=1e-4, atol=1e-2) and torch.allclose(got[:, 1], (flat * flat).sum(0), rtol=1e-4, atol=1e-2)
+    # the data-gradient use: explicit pads, accumulate into an existing gradient through the residual pointer
+    before = y2.float().cpu().double()
+    L.conv2d_fwd(L.make_conv_desc(xd, wd, y2, 3, 1, pads=(1, 1), out_hw=(H, W), residual=y2, tile=20))
+    torch.cuda.synchronize()
+    check(y2, before + conv, 2.0 ** -7, 3e-3)
+    # bit-identical to the per-patch kernel on integer-valued operands (any summation order is exact)
+    xi = torch.randint(-2, 3, (B, H, W, 32), generator=g).to(torch.bfloat16).to(dev)
+    wi = torch.randint(-1, 2, (Cout, 288), generator=g).to(torch.bfloat16).to(dev)
+    outs = []
+    for tile in (20, 2):
+        yo = torch.full((B, H, W, Cout), float("nan"), dtype=torch.bfloat16, device=dev)
+        L.conv2d_fwd(L.make_conv_desc(xi, wi, yo, 3, 1, residual=res.to(torch.bfloat16).to(dev), leaky=True, tile=tile))
+        torch.cuda.synchronize()
+        outs.append(yo)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
 def test_conv_residual_and_fused_concat(dev):
     g = torch.Generator().manual_seed(7)
     # residual (res_conv_bn, yolo/yolo3_net_pos.py:148-151): add AFTER the activation

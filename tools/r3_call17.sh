@@ -1,0 +1,4 @@
+python tools/dbg_stream.py 2>&1 | grep bad
+timeout 900 python -m pytest tests/test_gpu_conv.py tests/test_gpu_fullsize.py -x -q 2>&1 | tail -3
+timeout 600 python tools/bench_conv.py 8 576 16,20,0x202 2>&1 | grep "32, 64, 3, 1"
+timeout 600 python tools/bench_conv.py 32 576 16,20,0x202 2>&1 | grep "32, 64, 3, 1"
