@@ -1319,6 +1319,227 @@ __global__ __launch_bounds__(NW * 64) void conv_stream_kernel(ConvParams p, int 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming 1x1 convolution for the wide, shallow layers (Cout <= 64, K = C0 + C1 <= 192, hundreds of thousands of
+// pixels: conv3 / 6 / 8 / 77 / 79 / 80 / 82 and their data gradients), whose time is HBM traffic: 0.1-0.5 GFLOP per
+// 30-130 MB.  The GEMM kernel spends it on per-block fixed costs (offset tables, a 2-6 step K loop that never reaches
+// its pipeline's steady state, one round trip per phase); here nothing is staged through LDS and nothing is shared:
+//   * every WAVE is on its own: it walks over groups of 32 pixels (two 16-pixel MFMA fragments), fetches their K
+//     channels straight into B-operand fragments -- lane (pixel = lane & 15, chunk = lane >> 4) loads the 16 bytes
+//     [k*32 + 8*chunk, +8) of its pixel, all loads of a group issued before the first is used -- no barrier anywhere
+//     in the loop; the input is read exactly once and used by exactly one wave, so a trip through LDS would only add
+//     latency;
+//   * the weights (<= 24 KB) sit in LDS for the whole (persistent) block, rows padded by 16 bytes (conflict-free
+//     ds_read_b128 for every K this kernel takes);
+//   * fused nearest-upsample + concat: the second source's address is just another per-lane address;
+//   * the epilogue (scale / shift / leaky / residual / f32 or bf16) leaves bf16 rows through a per-wave LDS tile as
+//     whole 16-byte chunks; batch-norm statistics are accumulated in registers over ALL groups of the wave and leave
+//     as ONE partial row per block.
+// Latency is hidden by occupancy (16 waves per CU, ~10 KB of loads in flight each), not by a software pipeline.
+template <int NI>
+__global__ __launch_bounds__(512) void conv1x1_stream_kernel(ConvParams p, int ngroups) {
+  constexpr int NW = 8, U = 2;
+  constexpr int BN = NI * 16;
+  constexpr int ROWP = BN * 2 + 16;
+  constexpr int STG = U * 16 * ROWP;        // per-wave staging tile
+  constexpr int MAXKS = 6;                  // K <= 192
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 15, cq = lane >> 4;
+  const int K = p.K, ks32 = K >> 5;
+  const int wpitch = K * 2 + 16;
+  char* const wl = smem;                                        // weights [BN][wpitch]
+  char* const stg = smem + ((BN * wpitch + 15) & ~15);          // staging tiles, then the statistics scratch
+  // ---- weights -> LDS (once): 16-byte chunks, rows >= Cout are zero
+  for (int c = tid; c < BN * (K >> 3); c += NW * 64) {
+    const int n = c / (K >> 3), kc = c - n * (K >> 3);
+    uint4 v = uint4{0, 0, 0, 0};
+    if (n < p.Cout) v = *reinterpret_cast<const uint4*>(p.w + (size_t)n * K + kc * 8);
+    *reinterpret_cast<uint4*>(wl + n * wpitch + kc * 16) = v;
+  }
+  // per-channel scale / shift of this lane's 4 channels per N fragment
+  float esc[NI][4], esh[NI][4];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = j * 16 + cq * 4 + r;
+      esc[j][r] = (p.scale && n < p.Cout) ? p.scale[n] : 1.f;
+      esh[j][r] = (p.shift && n < p.Cout) ? p.shift[n] : 0.f;
+    }
+  __syncthreads();
+  const bool f32out = p.flags & DISYOLO_CONV_OUT_F32;
+  const bool do_stats = p.flags & DISYOLO_CONV_STATS;
+  const bool vec_ok = (p.Cout & 7) == 0;
+  const bool use_res = p.residual != nullptr;
+  const int H1 = p.H >> 1, W1 = p.W >> 1;
+  const int ks0 = p.C0 >> 5;                 // K steps that read source 0
+  float s1[NI][4], s2[NI][4];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[j][r] = s2[j][r] = 0.f;
+  char* const sw = stg + wave * STG;
+
+  for (int g = blockIdx.x * NW + wave; g < ngroups; g += gridDim.x * NW) {
+    // ---- fetch: U fragments x ks32 chunks of 16 bytes per lane
+    int m_of[U];
+    bf16x8 xf[U][MAXKS];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = g * (U * 16) + u * 16 + frow;
+      m_of[u] = m < p.M ? m : -1;
+      const int mm = m < p.M ? m : 0;
+      const bf16* a0 = p.x0 + (size_t)mm * p.C0 + cq * 8;
+      const bf16* a1 = a0;
+      if (p.C1 > 0) {
+        int b, rem, y, x;
+        divmod_small(mm, p.H * p.W, b, rem);
+        divmod_small(rem, p.W, y, x);
+        a1 = p.x1 + ((size_t)(b * H1 + (y >> 1)) * W1 + (x >> 1)) * p.C1 + cq * 8;
+      }
+#pragma unroll
+      for (int k = 0; k < MAXKS; ++k)
+        if (k < ks32) xf[u][k] = *reinterpret_cast<const bf16x8*>(k < ks0 ? a0 + k * 32 : a1 + (k - ks0) * 32);
+    }
+    uint2 rres[U][NI];
+    if (use_res) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int n = j * 16 + cq * 4;
+          rres[u][j] = *reinterpret_cast<const uint2*>(p.residual + (size_t)(m_of[u] >= 0 ? m_of[u] : 0) * p.Cout + (n + 3 < p.Cout ? n : 0));
+        }
+    }
+    // ---- multiply
+    f32x4 acc[U][NI];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < MAXKS; ++k) {
+      if (k < ks32) {
+        bf16x8 wf[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(wl + (j * 16 + frow) * wpitch + (k * 4 + cq) * 16);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[u][k], acc[u][j], 0, 0, 0);
+      }
+    }
+    // ---- epilogue.  acc[u][j][r]: pixel m_of[u], channel j*16 + 4*cq + r
+    if (do_stats) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = m_of[u] >= 0 ? acc[u][j][r] : 0.f;
+            s1[j][r] += v;
+            s2[j][r] += v * v;
+          }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = j * 16 + cq * 4;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[u][j][r] * esc[j][r] + esh[j][r];
+          if (p.flags & DISYOLO_CONV_LEAKY) v[r] = leaky(v[r], p.alpha);
+        }
+        if (use_res && n + 3 < p.Cout) {
+          const uint2 rr = rres[u][j];
+          v[0] += __builtin_bit_cast(float, rr.x << 16);
+          v[1] += __builtin_bit_cast(float, rr.x & 0xffff0000u);
+          v[2] += __builtin_bit_cast(float, rr.y << 16);
+          v[3] += __builtin_bit_cast(float, rr.y & 0xffff0000u);
+        }
+        if (f32out || !vec_ok) {
+          if (m_of[u] >= 0) {
+            const size_t off = (size_t)m_of[u] * p.Cout + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (n + r < p.Cout) {
+                float o = v[r];
+                if (use_res && !(n + 3 < p.Cout)) o += (float)p.residual[off + r];
+                if (f32out)
+                  reinterpret_cast<float*>(p.y)[off + r] = o;
+                else
+                  reinterpret_cast<bf16*>(p.y)[off + r] = (bf16)o;
+              }
+          }
+        } else {
+          uint2 o2;
+          o2.x = pack2(v[0], v[1]);
+          o2.y = pack2(v[2], v[3]);
+          *reinterpret_cast<uint2*>(sw + (u * 16 + frow) * ROWP + n * 2) = o2;
+        }
+      }
+    if (!(f32out || !vec_ok)) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      constexpr int CPR8 = BN / 8;                       // 16-byte chunks per staged row
+      constexpr int RPF = (U * 16 * CPR8 + 63) / 64;
+      const int cpr = p.Cout >> 3;                       // chunks per real row
+      bf16* yo = reinterpret_cast<bf16*>(p.y);
+#pragma unroll
+      for (int r_ = 0; r_ < RPF; ++r_) {
+        const int idx = r_ * 64 + lane;
+        const int row = idx / CPR8, ch = idx % CPR8;
+        const int m = g * (U * 16) + row;
+        if (idx < U * 16 * CPR8 && ch < cpr && m < p.M)
+          *reinterpret_cast<uint4*>(yo + (size_t)m * p.Cout + ch * 8) = *reinterpret_cast<const uint4*>(sw + row * ROWP + ch * 16);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();                   // the tile is free for the wave's next group
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  if (do_stats) {
+    // lanes of one channel quad -> waves (fixed order through LDS) -> ONE row of partials per block
+    float* red = reinterpret_cast<float*>(stg + NW * STG);       // [NW][BN][2]
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = s1[j][r], b2 = s2[j][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          a += __shfl_xor(a, o, 64);
+          b2 += __shfl_xor(b2, o, 64);
+        }
+        if (frow == 0) {
+          const int nl = j * 16 + cq * 4 + r;
+          red[(wave * BN + nl) * 2 + 0] = a;
+          red[(wave * BN + nl) * 2 + 1] = b2;
+        }
+      }
+    __syncthreads();
+    for (int nl = tid; nl < BN; nl += NW * 64) {
+      if (nl < p.Cout) {
+        float a = 0.f, b2 = 0.f;
+#pragma unroll
+        for (int w_ = 0; w_ < NW; ++w_) {
+          a += red[(w_ * BN + nl) * 2 + 0];
+          b2 += red[(w_ * BN + nl) * 2 + 1];
+        }
+        p.stats[((size_t)blockIdx.x * p.Cout + nl) * 2 + 0] = a;
+        p.stats[((size_t)blockIdx.x * p.Cout + nl) * 2 + 1] = b2;
+      }
+    }
+  }
+}
+
 // patch of the halo kernel for an H x W image: PH | H, PW | W, at most max_frags*16 output
 // pixels and max_halo halo pixels; the largest area wins, then the squarest.  0 = none fits.
 struct Patch {
@@ -1399,6 +1620,42 @@ int launch_stream(const ConvParams& p, Patch pt, hipStream_t s) {
                      tilesX, G);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
+}
+
+// tile id 21: the streaming 1x1 kernel (stride 1, Cout <= 64, K = C0 + C1 <= 192; any epilogue but the fused BN
+// backward sums).  Its grid -- and with it the number of statistics rows -- depends on the pixel count only.
+bool stream1x1_ok(const disyolo_conv_desc* d) {
+  if (d->ksize != 1 || d->stride != 1 || d->in_div != 1 || d->Ho != d->H || d->Wo != d->W) return false;
+  if (d->Cout > 64 || d->C0 % 32 || d->C1 % 32 || d->C0 + d->C1 > 192) return false;
+  if (d->flags & DISYOLO_CONV_BN_BWD_STATS) return false;
+  return true;
+}
+int stream1x1_blocks(int M) {
+  const int groups = ceil_div(M, 32);
+  int blocks = ceil_div(groups, 8 * 4);       // >= 4 groups per wave
+  if (blocks > 512) blocks = 512;             // two persistent blocks per CU
+  if (blocks < 1) blocks = 1;
+  return blocks;
+}
+template <int NI>
+int launch_stream1x1_n(const ConvParams& p, hipStream_t s) {
+  constexpr int BN = NI * 16;
+  const size_t wbytes = ((size_t)BN * (p.K * 2 + 16) + 15) & ~(size_t)15;
+  const size_t lds = wbytes + (size_t)8 * 2 * 16 * (BN * 2 + 16) + (size_t)8 * BN * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_kernel<NI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(64 * (192 * 2 + 16) + 8 * 2 * 16 * (64 * 2 + 16) + 8 * 64 * 8));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv1x1_stream_kernel<NI>), dim3(stream1x1_blocks(p.M)), dim3(512), lds, s, p, ceil_div(p.M, 32));
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+int launch_stream1x1(const ConvParams& p, hipStream_t s) {
+  if (p.Cout <= 16) return launch_stream1x1_n<1>(p, s);
+  if (p.Cout <= 32) return launch_stream1x1_n<2>(p, s);
+  return launch_stream1x1_n<4>(p, s);
 }
 
 template <int NW, int FW, int NI>
@@ -1577,13 +1834,17 @@ extern "C" size_t disyolo_conv_desc_size(void) { return sizeof(disyolo_conv_desc
 extern "C" int disyolo_conv2d_bn_bwd_stats_ok(const disyolo_conv_desc* d) {
   if (!d || (d->flags & DISYOLO_CONV_OUT_F32) || d->Cout % 8) return 0;
   const int sel = pick_tile(d, d->B * d->Ho * d->Wo);
-  return (sel & 0xff) >= 16 && (sel & 0xff) != 20 && halo_ok(d, sel & 0xff, nullptr) ? 1 : 0;
+  return (sel & 0xff) >= 16 && (sel & 0xff) < 20 && halo_ok(d, sel & 0xff, nullptr) ? 1 : 0;
 }
 
 extern "C" int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d) {
   if (!d) return DISYOLO_E_ARG;
   const int M = d->B * d->Ho * d->Wo;
   int sel = pick_tile(d, M);
+  if ((sel & 0xff) == 21) {
+    if (stream1x1_ok(d)) return stream1x1_blocks(M);
+    sel = pick_auto(d, M);
+  }
   if ((sel & 0xff) >= 16) {
     Patch pt;
     if ((sel & 0xff) == 20 ? stream_ok(d, &pt) : halo_ok(d, sel & 0xff, &pt)) return d->B * (d->H / pt.ph) * (d->W / pt.pw);
@@ -1606,6 +1867,16 @@ static int tile_stages(int id, bool bk64, int variant) {
 extern "C" int disyolo_conv2d_tile(const disyolo_conv_desc* d, int* bm, int* bn, int* bk, int* stages) {
   if (!d) return DISYOLO_E_ARG;
   int sel = pick_tile(d, d->B * d->Ho * d->Wo);
+  if ((sel & 0xff) == 21) {
+    if (stream1x1_ok(d)) {
+      if (bm) *bm = 32;
+      if (bn) *bn = d->Cout <= 16 ? 16 : (d->Cout <= 32 ? 32 : 64);
+      if (bk) *bk = 32;
+      if (stages) *stages = 1;
+      return 21;
+    }
+    sel = pick_auto(d, d->B * d->Ho * d->Wo);
+  }
   if ((sel & 0xff) >= 16) {
     Patch pt;
     if ((sel & 0xff) == 20 ? stream_ok(d, &pt) : halo_ok(d, sel & 0xff, &pt)) {
@@ -1673,6 +1944,10 @@ extern "C" int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream) {
   // tile field: low byte = tile id (0 = auto); bit 8 forces BK = 32, bit 9 selects the
   // alternative pipeline depth (tuning / testing)
   int sel = pick_tile(d, p.M);
+  if ((sel & 0xff) == 21) {
+    if (stream1x1_ok(d)) return launch_stream1x1(p, s);
+    sel = pick_auto(d, p.M);   // shape not covered by the streaming 1x1 kernel
+  }
   if ((sel & 0xff) == 20) {
     Patch pt;
     if (stream_ok(d, &pt)) return launch_stream(p, pt, s);

@@ -78,7 +78,8 @@ typedef struct disyolo_conv_desc {
                              kernel with 8/4 waves, 18 = 16 with 32 instead of 64 output
                              channels per block, 20 = the persistent streaming form of
                              the patch kernel for 3x3 stride-1 layers with exactly 32
-                             input channels; an id that does not cover the shape
+                             input channels, 21 = the streaming 1x1 kernel (stride 1,
+                             Cout <= 64, C0 + C1 <= 192); an id that does not cover the shape
                              falls back), bit 8 = force K depth 32, bit 9 = the tile's
                              alternative pipeline depth                              */
   const void* x0;         /* bf16 [B,H,W,C0]                                          */

@@ -211,6 +211,61 @@ def test_conv_stream_kernel_32_input_channels(dev, B, H, W, Cout):
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
 
 
+@pytest.mark.parametrize("B,H,W,C0,C1,Cout", [(2, 36, 36, 64, 0, 32), (1, 72, 48, 128, 64, 64), (3, 24, 40, 64, 32, 32),
+                                              (2, 50, 30, 64, 0, 9), (1, 144, 144, 128, 0, 64), (2, 18, 18, 32, 0, 64),
+                                              (1, 30, 22, 128, 0, 40)])
+def test_conv1x1_stream_kernel(dev, B, H, W, C0, C1, Cout):
+    """tile 21, the wave-autonomous streaming 1x1 kernel: folded BN + leaky (+ residual), fused upsample + concat, the
+    linear f32 form with a bias and 9 channels (conv82), training-mode statistics (one row per block), an accumulating
+    data gradient, ragged pixel counts and channel tiles -- against the f64 conv"""
+    g = torch.Generator().manual_seed(B * 100 + H + Cout + C1)
+    x0 = bf16r(torch.randn(B, H, W, C0, generator=g))
+    x1 = bf16r(torch.randn(B, H // 2, W // 2, C1, generator=g)) if C1 else None
+    w = bf16r(torch.randn(1, 1, C0 + C1, Cout, generator=g) / (C0 + C1) ** 0.5)
+    xin = torch.cat([x0, O.upsample2(x1)], -1) if C1 else x0
+    conv = O.conv2d_same(xin, w, 1)
+    x0d = x0.to(torch.bfloat16).to(dev)
+    x1d = x1.to(torch.bfloat16).to(dev) if C1 else None
+    wd = pack_ref(w).to(torch.bfloat16).to(dev)
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.3
+    if Cout % 8 == 0:
+        res = bf16r(torch.randn(B, H, W, Cout, generator=g))
+        y = torch.full((B, H, W, Cout), float("nan"), dtype=torch.bfloat16, device=dev)
+        d = L.make_conv_desc(x0d, wd, y, 1, 1, x1=x1d, scale=scale.to(dev), shift=shift.to(dev), residual=res.to(torch.bfloat16).to(dev),
+                             leaky=True, tile=21)
+        assert L.conv2d_tile(d)[0] == 21
+        L.conv2d_fwd(d)
+        torch.cuda.synchronize()
+        check(y, O.leaky_relu(conv * scale.double() + shift.double(), 0.1) + res, 2.0 ** -7, 2e-3)
+        # training-mode batch norm: raw output + statistics partials
+        y2 = torch.full((B, H, W, Cout), float("nan"), dtype=torch.bfloat16, device=dev)
+        rows = L.conv2d_stats_rows(L.make_conv_desc(x0d, wd, y2, 1, 1, x1=x1d, tile=21))
+        stats = torch.full((rows, Cout, 2), float("nan"), dtype=torch.float32, device=dev)
+        L.conv2d_fwd(L.make_conv_desc(x0d, wd, y2, 1, 1, x1=x1d, stats=stats, tile=21))
+        torch.cuda.synchronize()
+        check(y2, conv, 2.0 ** -7, 1e-3)
+        flat = conv.reshape(-1, Cout)
+        got = stats.double().sum(0).cpu()
+        assert torch.allclose(got[:, 0], flat.sum(0), rtol=1e-4, atol=1e-2) and torch.allclose(got[:, 1], (flat * flat).sum(0), rtol=1e-4, atol=1e-2)
+        if not C1:
+            before = y2.float().cpu().double()
+            L.conv2d_fwd(L.make_conv_desc(x0d, wd, y2, 1, 1, residual=y2, tile=21))       # y += conv: the data-gradient use
+            torch.cuda.synchronize()
+            check(y2, before + conv, 2.0 ** -7, 3e-3)
+    # linear f32 output with a bias (conv59 / 67 / 75 / 82)
+    yf = torch.full((B, H, W, Cout), float("nan"), dtype=torch.float32, device=dev)
+    L.conv2d_fwd(L.make_conv_desc(x0d, wd, yf, 1, 1, x1=x1d, shift=shift.to(dev), out_f32=True, tile=21))
+    torch.cuda.synchronize()
+    want = conv + shift.double()
+    check(yf, want, 1e-5, 1e-4 * float(want.abs().max()))
+    # bf16 output with a ragged channel count goes element by element
+    yb = torch.full((B, H, W, Cout), float("nan"), dtype=torch.bfloat16, device=dev)
+    L.conv2d_fwd(L.make_conv_desc(x0d, wd, yb, 1, 1, x1=x1d, scale=scale.to(dev), shift=shift.to(dev), leaky=True, tile=21))
+    torch.cuda.synchronize()
+    check(yb, O.leaky_relu(conv * scale.double() + shift.double(), 0.1), 2.0 ** -7, 2e-3)
+
+
 def test_conv_residual_and_fused_concat(dev):
     g = torch.Generator().manual_seed(7)
     # residual (res_conv_bn, yolo/yolo3_net_pos.py:148-151): add AFTER the activation
