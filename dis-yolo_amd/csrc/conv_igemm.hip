@@ -1831,26 +1831,43 @@ int validate(const disyolo_conv_desc* d) {
 
 extern "C" size_t disyolo_conv_desc_size(void) { return sizeof(disyolo_conv_desc); }
 
+// The tile code that will actually run: d->tile (or the heuristic) with every "this id does not cover the shape"
+// fallback applied -- ONE place, so that the launcher, the statistics-row count and the reported tile cannot disagree.
+// ids >= 16 return their patch in *pt.
+static int resolve_sel(const disyolo_conv_desc* d, int M, Patch* pt) {
+  Patch tmp;
+  if (!pt) pt = &tmp;
+  int sel = pick_tile(d, M);
+  for (int guard = 0; guard < 3; ++guard) {
+    const int id = sel & 0xff;
+    if (id == 21) {
+      if (stream1x1_ok(d)) return sel;
+    } else if (id == 20) {
+      if (stream_ok(d, pt)) return sel;
+    } else if (id >= 16) {
+      if (halo_ok(d, id, pt)) return sel;
+    } else {
+      return sel;
+    }
+    sel = pick_auto(d, M);     // (returns a patch tile only where it covers the shape)
+  }
+  return sel;
+}
+
 extern "C" int disyolo_conv2d_bn_bwd_stats_ok(const disyolo_conv_desc* d) {
   if (!d || (d->flags & DISYOLO_CONV_OUT_F32) || d->Cout % 8) return 0;
-  const int sel = pick_tile(d, d->B * d->Ho * d->Wo);
-  return (sel & 0xff) >= 16 && (sel & 0xff) < 20 && halo_ok(d, sel & 0xff, nullptr) ? 1 : 0;
+  const int id = resolve_sel(d, d->B * d->Ho * d->Wo, nullptr) & 0xff;
+  return id >= 16 && id < 20 ? 1 : 0;
 }
 
 extern "C" int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d) {
   if (!d) return DISYOLO_E_ARG;
   const int M = d->B * d->Ho * d->Wo;
-  int sel = pick_tile(d, M);
-  if ((sel & 0xff) == 21) {
-    if (stream1x1_ok(d)) return stream1x1_blocks(M);
-    sel = pick_auto(d, M);
-  }
-  if ((sel & 0xff) >= 16) {
-    Patch pt;
-    if ((sel & 0xff) == 20 ? stream_ok(d, &pt) : halo_ok(d, sel & 0xff, &pt)) return d->B * (d->H / pt.ph) * (d->W / pt.pw);
-    sel = pick_auto(d, M);
-  }
-  const int bm = tile_bm(sel & 0xff);
+  Patch pt;
+  const int id = resolve_sel(d, M, &pt) & 0xff;
+  if (id == 21) return stream1x1_blocks(M);
+  if (id >= 16) return d->B * (d->H / pt.ph) * (d->W / pt.pw);
+  const int bm = tile_bm(id);
   if (bm == 0) return DISYOLO_E_ARG;
   return ceil_div(M, bm);
 }
@@ -1866,27 +1883,21 @@ static int tile_stages(int id, bool bk64, int variant) {
 
 extern "C" int disyolo_conv2d_tile(const disyolo_conv_desc* d, int* bm, int* bn, int* bk, int* stages) {
   if (!d) return DISYOLO_E_ARG;
-  int sel = pick_tile(d, d->B * d->Ho * d->Wo);
+  Patch pt;
+  const int sel = resolve_sel(d, d->B * d->Ho * d->Wo, &pt);
   if ((sel & 0xff) == 21) {
-    if (stream1x1_ok(d)) {
-      if (bm) *bm = 32;
-      if (bn) *bn = d->Cout <= 16 ? 16 : (d->Cout <= 32 ? 32 : 64);
-      if (bk) *bk = 32;
-      if (stages) *stages = 1;
-      return 21;
-    }
-    sel = pick_auto(d, d->B * d->Ho * d->Wo);
+    if (bm) *bm = 32;
+    if (bn) *bn = d->Cout <= 16 ? 16 : (d->Cout <= 32 ? 32 : 64);
+    if (bk) *bk = 32;
+    if (stages) *stages = 1;
+    return 21;
   }
   if ((sel & 0xff) >= 16) {
-    Patch pt;
-    if ((sel & 0xff) == 20 ? stream_ok(d, &pt) : halo_ok(d, sel & 0xff, &pt)) {
-      if (bm) *bm = pt.ph * pt.pw;
-      if (bn) *bn = halo_bn(sel & 0xff);
-      if (bk) *bk = 32;
-      if (stages) *stages = 2;
-      return sel & 0xff;
-    }
-    sel = pick_auto(d, d->B * d->Ho * d->Wo);
+    if (bm) *bm = pt.ph * pt.pw;
+    if (bn) *bn = halo_bn(sel & 0xff);
+    if (bk) *bk = 32;
+    if (stages) *stages = 2;
+    return sel & 0xff;
   }
   const bool bk64 = (d->C0 % 64 == 0) && (d->C1 % 64 == 0) && !(sel & 0x100);
   const int id = resolve_tile(sel & 0xff, bk64, d->ksize * d->ksize * (d->C0 + d->C1));
@@ -1943,22 +1954,15 @@ extern "C" int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   // tile field: low byte = tile id (0 = auto); bit 8 forces BK = 32, bit 9 selects the
   // alternative pipeline depth (tuning / testing)
-  int sel = pick_tile(d, p.M);
-  if ((sel & 0xff) == 21) {
-    if (stream1x1_ok(d)) return launch_stream1x1(p, s);
-    sel = pick_auto(d, p.M);   // shape not covered by the streaming 1x1 kernel
-  }
-  if ((sel & 0xff) == 20) {
-    Patch pt;
-    if (stream_ok(d, &pt)) return launch_stream(p, pt, s);
-    sel = pick_auto(d, p.M);   // shape not covered by the streaming kernel
-  }
-  if ((sel & 0xff) >= 16) {
-    Patch pt;
-    if (halo_ok(d, sel & 0xff, &pt))
-      return (sel & 0xff) == 16 ? launch_halo<8, 3, 4>(p, pt, s)
-             : (sel & 0xff) == 18 ? launch_halo<8, 3, 2>(p, pt, s) : launch_halo<4, 3, 4>(p, pt, s);
-    sel = pick_auto(d, p.M);   // shape not covered by the patch kernel
+  Patch pt;
+  const int sel = resolve_sel(d, p.M, &pt);
+  switch (sel & 0xff) {
+    case 21: return launch_stream1x1(p, s);
+    case 20: return launch_stream(p, pt, s);
+    case 16: return launch_halo<8, 3, 4>(p, pt, s);
+    case 18: return launch_halo<8, 3, 2>(p, pt, s);
+    case 17: return launch_halo<4, 3, 4>(p, pt, s);
+    default: break;
   }
   const bool bk64 = (d->C0 % 64 == 0) && (d->C1 % 64 == 0) && !(sel & 0x100);
   return dispatch(sel & 0xff, bk64, (sel >> 9) & 1, p, s);
