@@ -42,7 +42,7 @@ MFMA_PEAK_TFLOPS = 2500.0      # bf16 dense, MI355X_MICROARCH.md "Peak BF16/FP16
 
 
 HBM_PEAK_TBS = 8.0             # spec; ~6.3 TB/s measured copy
-PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"
 
 
 def bound_model(B: int, S: int, stage: int):
@@ -490,6 +490,20 @@ def main():
                                "flops_per_launch_unit": "GFLOP (algorithmic, 2*M*N*K averaged over this kernel's launches)",
                                "avg_launch_us": round(r["ms_total"] / r["launches"] * 1e3, 2),
                                "launches_per_step": r["launches"] / args.steps}
+            # the conv instance below the ridge (algorithmic FLOP per byte < 2.5 PF / 8 TB/s) with the largest total time:
+            # what it reaches of the HBM roofline, from the same HIP-event timings
+            ridge = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_TBS * 1e12)
+            hb = {k: r for k, r in summ.items() if r.get("bytes_total", 0) > 0 and r["flops_total"] / r["bytes_total"] < ridge}
+            if hb:
+                hk = max(hb, key=lambda k: hb[k]["ms_total"])
+                r = hb[hk]
+                gbs = r["bytes_total"] / (r["ms_total"] * 1e-3) / 1e9
+                out["roofline"]["hbm_bound_instance"] = {
+                    "kernel": hk, "achieved": round(gbs, 1), "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
+                    "hbm_frac": round(gbs / (HBM_PEAK_TBS * 1e3), 4), "launches_per_step": r["launches"] / args.steps,
+                    "avg_launch_us": round(r["ms_total"] / r["launches"] * 1e3, 2),
+                    "bytes_per_launch": round(r["bytes_total"] / r["launches"]),
+                    "bytes_definition": "algorithmic: inputs + packed weights + output (+ residual), each once"}
             out["kernels"] = kernels
         if world == 1 and not args.no_secondary and args.stage == 1 and B == 8 and args.dtype == "bf16":
             del timer

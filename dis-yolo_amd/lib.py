@@ -381,21 +381,22 @@ class KernelTimer:
     def __init__(self):
         self.records = {}   # name -> [flops_total, [(start, end), ...]]
 
-    def run(self, name: str, flops: float, fn) -> None:
+    def run(self, name: str, flops: float, fn, nbytes: float = 0.0) -> None:
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
         fn()
         e.record()
-        rec = self.records.setdefault(name, [0.0, []])
+        rec = self.records.setdefault(name, [0.0, [], 0.0])
         rec[0] += flops
         rec[1].append((s, e))
+        rec[2] += nbytes
 
     def summary(self):
         out = {}
-        for name, (flops, evs) in self.records.items():
+        for name, (flops, evs, nbytes) in self.records.items():
             ms = sum(s.elapsed_time(e) for s, e in evs)
-            out[name] = {"launches": len(evs), "ms_total": ms, "flops_total": flops}
+            out[name] = {"launches": len(evs), "ms_total": ms, "flops_total": flops, "bytes_total": nbytes}
         return out
 
 
@@ -407,6 +408,14 @@ def conv_flops(d: ConvDesc) -> float:
     transposed (data-gradient) gather only 1/in_div^2 of the taps are real work"""
     K = d.ksize * d.ksize * (d.C0 + d.C1)
     return 2.0 * d.B * d.Ho * d.Wo * d.Cout * K / float(d.in_div * d.in_div)
+
+
+def conv_bytes(d: ConvDesc) -> float:
+    """algorithmic HBM bytes of one launch: input(s) + packed weights + output (+ the residual it adds), each once"""
+    K = d.ksize * d.ksize * (d.C0 + d.C1)
+    out_b = d.B * d.Ho * d.Wo * d.Cout * (4 if d.flags & CONV_OUT_F32 else 2)
+    return float(d.B * d.H * d.W * d.C0 * 2 + d.B * (d.H // 2) * (d.W // 2) * d.C1 * 2 + d.Cout * K * 2 + out_b
+                 + (d.B * d.Ho * d.Wo * d.Cout * 2 if d.residual else 0))
 
 
 _WAVES = {1: (2, 2), 2: (2, 2), 3: (2, 2), 4: (4, 1), 5: (4, 1), 6: (2, 2), 7: (4, 1), 8: (4, 2), 9: (2, 2),
@@ -439,7 +448,7 @@ def conv2d_fwd(d: ConvDesc) -> None:
                 d._tname = "conv_igemm_kernel<%d,%d,%d,%d,%d,%d,%d,%d>" % ((bm, bn) + _WAVES[tid] +
                                                                             (bk, st, d.ksize, 2 if tid >= 13 else 1))
         TIMER.run(d._tname, conv_flops(d), lambda: _check(load().disyolo_conv2d_fwd(C.byref(d), _stream()),
-                                                           "conv2d_fwd"))
+                                                           "conv2d_fwd"), conv_bytes(d))
         return
     _check(load().disyolo_conv2d_fwd(C.byref(d), _stream()), "conv2d_fwd")
 
