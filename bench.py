@@ -296,6 +296,9 @@ def main():
                          "table profiles/tune_<workload>.json when there is one for this workload (the run is then "
                          "bit-reproducible box to box and its losses are a regression canary), else tune live; "
                          "'none': always tune live")
+    ap.add_argument("--poison", action="store_true",
+                    help="self-test of the loss canary: a NaN is written into one trainable weight before the timed "
+                         "regions; the run must then FAIL (exit code 3, an \"error\" field, no throughput)")
     ap.add_argument("--force-dp", action="store_true",
                     help="initialise RCCL and run the bucketed gradient all-reduce path even with one rank (self-test)")
     ap.add_argument("--sync-bn", action="store_true",
@@ -386,6 +389,9 @@ def main():
         net.build_program(graph=(mode == "graph"), pipeline_backbone=pipe)
         if pipe:
             net.prime_pipeline()       # backbone of the first batch, outside the timed region
+    if args.poison:
+        net.arena[net.n_decay // 2] = float("nan")
+        net.refresh_weights()
     # losses are read OUTSIDE the timed regions: after the first recorded step, after the warm-up, after every region
     loss_trace = []
     for i in range(args.warmup):

@@ -111,3 +111,19 @@ def test_every_tile_candidate_agrees_on_every_launch_of_the_stage2_step(dev):
     nbad, n = tile_check.run(2, 8, 576, out=lines.append)
     assert n >= 50
     assert nbad == 0, "\n".join(ln for ln in lines if ln.startswith("BAD"))
+
+
+def test_bench_fails_on_a_non_finite_loss(dev):
+    """bench.py's canary: with a NaN planted in one weight the run exits with code 3, prints an "error" and no
+    throughput; the same command without it exits 0 with a finite loss_first / loss_last"""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "2", "--size", "64", "--steps", "2", "--warmup", "2",
+           "--repeats", "2", "--no-secondary", "--no-cpu-baseline", "--no-kernel-events", "--autotune", "off"]
+    ok = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+    line = json.loads([ln for ln in ok.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert ok.returncode == 0 and line["value"] > 0 and "error" not in line
+    assert np.isfinite(line["config"]["loss_first"]) and np.isfinite(line["config"]["loss_last"])
+    bad = subprocess.run(cmd + ["--poison"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+    line = json.loads([ln for ln in bad.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert bad.returncode == 3 and line["value"] is None and "non-finite" in line["error"]
