@@ -54,6 +54,8 @@ _SIGS = {
     "disyolo_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "disyolo_conv2d_tile": (C.c_int, [C.POINTER(ConvDesc)] + [C.POINTER(C.c_int)] * 4),
     "disyolo_conv_first_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
+    "disyolo_conv12_fused_ok": (C.c_int, [C.c_int] * 3),
+    "disyolo_conv12_fused_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
     "disyolo_conv2d_wgrad_workspace": (C.c_size_t, [C.POINTER(ConvDesc), C.c_int]),
     "disyolo_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_size_t, C.c_int, C.c_void_p]),
@@ -488,6 +490,24 @@ def dequant_fp8(x8, y, scale: float) -> None:
 
 def pack_weights_fp8(w_hwio, w8, ksize, cin, cout, scale: float) -> None:
     _check(load().disyolo_pack_weights_fp8(_p(w_hwio), _p(w8), ksize, cin, cout, scale, _stream()), "pack_weights_fp8")
+
+
+def conv12_fused_ok(B: int, H: int, W: int) -> bool:
+    return load().disyolo_conv12_fused_ok(B, H, W) == 1
+
+
+def conv12_fused_fwd(images, w1_hwio, scale1, shift1, w2_packed, scale2, shift2, y, alpha=0.1) -> None:
+    """conv1 + conv2 (both in inference mode) in one launch; conv1's output is not materialised"""
+    _need(images, torch.float32, "images")
+    _need(y, torch.bfloat16, "y")
+    B, H, W, _ = images.shape
+    fn = lambda: _check(load().disyolo_conv12_fused_fwd(_p(images), _p(w1_hwio), _p(scale1), _p(shift1), _p(w2_packed), _p(scale2),
+                                                        _p(shift2), _p(y), B, H, W, alpha, _stream()), "conv12_fused_fwd")
+    if TIMER is not None:
+        flops = 2.0 * B * H * W * 32 * 27 + 2.0 * B * (H // 2) * (W // 2) * 64 * 288
+        TIMER.run("conv12_fused_kernel", flops, fn, float(B * H * W * 12 + B * (H // 2) * (W // 2) * 128))
+        return
+    fn()
 
 
 def conv_first_fwd(images, w_hwio, scale, shift, y, alpha=0.1) -> None:

@@ -178,6 +178,10 @@ class YOLONet(object):
         self.opt_chunks = None      # slices of the arena the optimizer sweeps one by one (_plan_opt_chunks)
         self._side_streams = {}  # id(recorded list) -> its side lane as a torch stream
         self._progs = None      # [parity] -> (list, marks, bwd_end) of the pipelined step
+        # conv1 + conv2 as ONE launch wherever both run in inference mode (the locked backbone of stage 1, every inference
+        # net): conv1's output -- 170 MB at B = 8, one consumer, unused by the active mask subnet (yolo/yolo3_net_pos.py:163)
+        # -- is then never written, and ``by_idx[1].act`` is NOT filled.  Set to False to get every layer's output.
+        self.fuse_first_two = os.environ.get("DISYOLO_FUSE12", "1") != "0"
         self.use_side_lane = os.environ.get("DISYOLO_SIDE_LANE", "1") != "0"
         # debug mode of the fused batch-norm backward (set to a list): every layer whose backward sums come from the
         # data-gradient conv's epilogue ALSO runs the plain column reduction on the same gradient (eager steps only) and
@@ -539,8 +543,7 @@ class YOLONet(object):
         """run the backbone once for the images currently set (fills parity 0); afterwards every
         train_step consumes that result and computes the backbone of the NEXT images meanwhile"""
         self._use_parity(0)
-        for l in self.layers[:self._pipe_P]:
-            self._forward_layer(l, True)
+        self._forward_prefix(self._pipe_P, True)
         self._parity = 0
 
     def _build_dgrad_descs(self) -> None:
@@ -587,8 +590,13 @@ class YOLONet(object):
 
     def _forward_layers(self, is_training: bool, first: int = 1) -> None:
         B = self.B
+        fused12 = first <= 1 and self._can_fuse_first_two(is_training)
         for l in self.layers:
             if l.idx < first:
+                continue
+            if fused12 and l.idx <= 2:
+                if l.idx == 1:
+                    self._forward_first_two()
                 continue
             if self.use_side_lane:
                 if l.idx in self.HEAD_BRANCH:
@@ -600,6 +608,30 @@ class YOLONet(object):
         if self.use_side_lane:
             L.set_lane(0)
             L.lane_sync(1, 0)
+
+    def _forward_first_two(self) -> None:
+        l1, l2 = self.by_idx[1], self.by_idx[2]
+        L.conv12_fused_fwd(self.images, l1.w, l1.scale, l1.shift, l2.wp, l2.scale, l2.shift, l2.act, alpha=cfg.ALPHA)
+
+    def _forward_prefix(self, upto: int, is_training: bool) -> None:
+        """layers 1..upto one after the other on the current lane (the pipelined backbone), same kernels as
+        _forward_layers"""
+        fused12 = upto >= 2 and self._can_fuse_first_two(is_training)
+        for l in self.layers[:upto]:
+            if fused12 and l.idx <= 2:
+                if l.idx == 1:
+                    self._forward_first_two()
+                continue
+            self._forward_layer(l, is_training)
+
+    def _can_fuse_first_two(self, is_training: bool) -> bool:
+        """conv1 and conv2 both in inference mode (folded moving statistics), bf16 path, a size the fused kernel covers"""
+        if not self.fuse_first_two or (self.dtype == "fp8" and self.fp8_ready):
+            return False
+        l1, l2 = self.by_idx[1], self.by_idx[2]
+        if self.training and not (l1.lock and l2.lock):
+            return False            # (a trainable conv1 / conv2 needs its own output -- and its batch statistics)
+        return L.conv12_fused_ok(self.B, self.S, self.S)
 
     def _forward_layer(self, l, is_training: bool) -> None:
         B = self.B
@@ -1236,8 +1268,7 @@ class YOLONet(object):
                 lane = int(os.environ.get("DISYOLO_PIPE_LANE", "2"))
                 L.lane_sync(0, lane)
                 L.set_lane(lane)
-                for l in self.layers[:self._pipe_P]:
-                    self._forward_layer(l, True)
+                self._forward_prefix(self._pipe_P, True)
                 L.set_lane(0)
                 self._use_parity(parity)
             if self.dp is not None:

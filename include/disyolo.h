@@ -129,6 +129,17 @@ int disyolo_conv_first_fwd(const float* images, const float* w_hwio, const float
                            const float* shift, void* y_bf16, int B, int H, int W, int Cout,
                            float alpha, void* stream);
 
+/* conv1 + conv2 in one launch when both run in inference mode (locked / inference net): act2 = leaky(bn2(conv3x3 stride 2
+ * (leaky(bn1(conv3x3(images)))))), yolo/yolo3_net_pos.py:159-169 -- conv1's output (one consumer, the largest tensor of the
+ * network) is never written.  images f32 NHWC [B,H,W,3]; w1 f32 HWIO [3,3,3,32]; w2 bf16 packed [64][9*32] (pack_weights);
+ * folded BN scale / shift per layer; y bf16 [B,H/2,W/2,64].  conv1 runs on the bf16 matrix cores with hi/lo-split operands
+ * (relative error 2^-16 per product against exact f32, before the rounding to bf16).  disyolo_conv12_fused_ok: 1 when the
+ * sizes are covered (H/2 a multiple of 8, W/2 of 16). */
+int disyolo_conv12_fused_ok(int B, int H, int W);
+int disyolo_conv12_fused_fwd(const float* images, const float* w1_hwio, const float* scale1, const float* shift1,
+                             const void* w2_packed, const float* scale2, const float* shift2, void* y_bf16, int B, int H,
+                             int W, float alpha, void* stream);
+
 /* weight gradient (TF autodiff of tf.nn.conv2d wrt filters; train_yolo3_mask.py:55):
  * dw[kh,kw,ci,co] (f32 HWIO, overwritten) = sum_m xcol[m,(kh,kw,ci)] * dy[m,co].
  * Uses d->x0/x1 (the layer input, same gather as forward) and `dy` bf16 [B*Ho*Wo, dy_ld]

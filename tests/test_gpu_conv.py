@@ -344,6 +344,36 @@ def test_conv_first_layer(dev, B, H, W):
     check(y, want, 2.0 ** -8, 1e-5)
 
 
+@pytest.mark.parametrize("B,S", [(2, 64), (1, 96), (3, 32), (1, 160)])
+def test_conv12_fused_matches_the_two_layers(dev, B, S):
+    """conv1 + conv2 in one launch (inference-mode BN folded): against the f64 chain with conv1's output rounded to bf16
+    where the unfused path stores it, and against the unfused kernels themselves (conv1 on hi/lo-split bf16 operands is
+    2^-16 from exact f32, so a bf16 rounding of act1 flips now and then: act2 agrees bit for bit almost everywhere)"""
+    g = torch.Generator().manual_seed(S + B)
+    img = torch.rand(B, S, S, 3, generator=g)
+    w1 = torch.randn(3, 3, 3, 32, generator=g) * 0.3
+    w2 = bf16r(torch.randn(3, 3, 32, 64, generator=g) / 17)
+    sc1, sh1 = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.2
+    sc2, sh2 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    assert L.conv12_fused_ok(B, S, S)
+    a1 = bf16r(O.leaky_relu(O.conv2d_same(img.double(), w1.double(), 1) * sc1.double() + sh1.double(), 0.1).float())
+    want = O.leaky_relu(O.conv2d_same(a1.double(), w2.double(), 2) * sc2.double() + sh2.double(), 0.1)
+    w2p = pack_ref(w2).to(torch.bfloat16).to(dev)
+    y = torch.full((B, S // 2, S // 2, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    L.conv12_fused_fwd(img.to(dev), w1.to(dev), sc1.to(dev), sh1.to(dev), w2p, sc2.to(dev), sh2.to(dev), y, alpha=0.1)
+    torch.cuda.synchronize()
+    check(y, want, 2.0 ** -7, 3e-3)
+    # the unfused kernels on the same operands
+    y1 = torch.empty(B, S, S, 32, dtype=torch.bfloat16, device=dev)
+    L.conv_first_fwd(img.to(dev), w1.to(dev), sc1.to(dev), sh1.to(dev), y1, alpha=0.1)
+    y2 = torch.empty_like(y)
+    L.conv2d_fwd(L.make_conv_desc(y1, w2p, y2, 3, 2, scale=sc2.to(dev), shift=sh2.to(dev), leaky=True))
+    torch.cuda.synchronize()
+    same = float((y.view(torch.int16) == y2.view(torch.int16)).float().mean())
+    assert same > 0.97, same
+    assert float((y.float() - y2.float()).abs().max()) <= 2.0 ** -6 * float(y2.float().abs().max())
+
+
 def test_pack_weights(dev):
     g = torch.Generator().manual_seed(5)
     for k, cin, cout, pad in ((3, 64, 128, 128), (1, 96, 24, 32), (3, 32, 9, 32)):
