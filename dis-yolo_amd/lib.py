@@ -56,6 +56,9 @@ _SIGS = {
     "disyolo_conv_first_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "disyolo_conv12_fused_ok": (C.c_int, [C.c_int] * 3),
     "disyolo_conv12_fused_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
+    "disyolo_block32_fused_ok": (C.c_int, [C.c_int] * 6),
+    "disyolo_block32_fused_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int] +
+                                  [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
     "disyolo_conv2d_wgrad_workspace": (C.c_size_t, [C.POINTER(ConvDesc), C.c_int]),
     "disyolo_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_size_t, C.c_int, C.c_void_p]),
@@ -506,6 +509,30 @@ def conv12_fused_fwd(images, w1_hwio, scale1, shift1, w2_packed, scale2, shift2,
     if TIMER is not None:
         flops = 2.0 * B * H * W * 32 * 27 + 2.0 * B * (H // 2) * (W // 2) * 64 * 288
         TIMER.run("conv12_fused_kernel", flops, fn, float(B * H * W * 12 + B * (H // 2) * (W // 2) * 128))
+        return
+    fn()
+
+
+def block32_fused_ok(B: int, H: int, W: int, C0: int, C1: int, post: int) -> bool:
+    return load().disyolo_block32_fused_ok(B, H, W, C0, C1, post) == 1
+
+
+def block32_fused_fwd(x0, x1, wA, scaleA, shiftA, wB, scaleB, shiftB, y, post=0, wC=None, biasC=None, alpha=0.1) -> None:
+    """[1x1 (C0 + up2(C1)) -> 32] -> [3x3 32 -> 64] with folded batch norms in one launch; post 0: + residual x0 -> bf16 y
+    (the first residual block), post 1: -> [1x1 64 -> 9] + bias -> f32 y (the mask head).  The 32- and 64-channel
+    intermediates are not materialised."""
+    _need(x0, torch.bfloat16, "x0")
+    _need(y, torch.bfloat16 if post == 0 else torch.float32, "y")
+    B, H, W, C0 = x0.shape
+    C1 = 0 if x1 is None else x1.shape[-1]
+    fn = lambda: _check(load().disyolo_block32_fused_fwd(_p(x0), _p(x1), C0, C1, _p(wA), _p(scaleA), _p(shiftA), _p(wB), _p(scaleB),
+                                                         _p(shiftB), post, _p(wC), _p(biasC), _p(y), B, H, W, alpha, _stream()),
+                        "block32_fused_fwd")
+    if TIMER is not None:
+        M = B * H * W
+        flops = 2.0 * M * (32 * (C0 + C1) + 64 * 288 + (64 * 9 if post else 0))
+        nbytes = M * C0 * 2 + (M // 4) * C1 * 2 + (M * 36 if post else M * 128)
+        TIMER.run("block32_kernel<%d,%d>" % (C0 + C1, post), flops, fn, float(nbytes))
         return
     fn()
 

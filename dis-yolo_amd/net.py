@@ -182,6 +182,7 @@ class YOLONet(object):
         # net): conv1's output -- 170 MB at B = 8, one consumer, unused by the active mask subnet (yolo/yolo3_net_pos.py:163)
         # -- is then never written, and ``by_idx[1].act`` is NOT filled.  Set to False to get every layer's output.
         self.fuse_first_two = os.environ.get("DISYOLO_FUSE12", "1") != "0"
+        self.fuse_blocks = os.environ.get("DISYOLO_FUSE_BLOCKS", "1") != "0"
         self.use_side_lane = os.environ.get("DISYOLO_SIDE_LANE", "1") != "0"
         # debug mode of the fused batch-norm backward (set to a list): every layer whose backward sums come from the
         # data-gradient conv's epilogue ALSO runs the plain column reduction on the same gradient (eager steps only) and
@@ -589,14 +590,9 @@ class YOLONet(object):
     HEAD_LAYERS = (58, 59, 66, 67, 74, 75)
 
     def _forward_layers(self, is_training: bool, first: int = 1) -> None:
-        B = self.B
-        fused12 = first <= 1 and self._can_fuse_first_two(is_training)
+        plan = self._fusion_plan(is_training, first, 82)
         for l in self.layers:
             if l.idx < first:
-                continue
-            if fused12 and l.idx <= 2:
-                if l.idx == 1:
-                    self._forward_first_two()
                 continue
             if self.use_side_lane:
                 if l.idx in self.HEAD_BRANCH:
@@ -604,6 +600,10 @@ class YOLONet(object):
                     L.set_lane(1)
                 elif l.idx in (60, 68, 76):
                     L.set_lane(0)
+            if l.idx in plan:
+                if plan[l.idx] is not None:
+                    plan[l.idx]()
+                continue
             self._forward_layer(l, is_training)
         if self.use_side_lane:
             L.set_lane(0)
@@ -613,23 +613,55 @@ class YOLONet(object):
         l1, l2 = self.by_idx[1], self.by_idx[2]
         L.conv12_fused_fwd(self.images, l1.w, l1.scale, l1.shift, l2.wp, l2.scale, l2.shift, l2.act, alpha=cfg.ALPHA)
 
+    def _forward_block34(self) -> None:
+        l2, l3, l4 = self.by_idx[2], self.by_idx[3], self.by_idx[4]
+        L.block32_fused_fwd(l2.act, None, l3.wp, l3.scale, l3.shift, l4.wp, l4.scale, l4.shift, l4.act, post=0, alpha=cfg.ALPHA)
+
+    def _forward_mask_head(self) -> None:
+        l80, l81, l82 = self.by_idx[80], self.by_idx[81], self.by_idx[82]
+        L.block32_fused_fwd(self.by_idx[l80.src].act, self.by_idx[l80.src_up].act, l80.wp, l80.scale, l80.shift, l81.wp, l81.scale,
+                            l81.shift, l82.act, post=1, wC=l82.wp, biasC=l82.bias, alpha=cfg.ALPHA)
+
     def _forward_prefix(self, upto: int, is_training: bool) -> None:
         """layers 1..upto one after the other on the current lane (the pipelined backbone), same kernels as
         _forward_layers"""
-        fused12 = upto >= 2 and self._can_fuse_first_two(is_training)
+        plan = self._fusion_plan(is_training, 1, upto)
         for l in self.layers[:upto]:
-            if fused12 and l.idx <= 2:
-                if l.idx == 1:
-                    self._forward_first_two()
+            if l.idx in plan:
+                if plan[l.idx] is not None:
+                    plan[l.idx]()
                 continue
             self._forward_layer(l, is_training)
+
+    def _inference_mode(self, idxs, is_training: bool) -> bool:
+        """every one of these layers normalises with its folded moving statistics in this pass"""
+        return all(self.by_idx[i].kind == "lin" or not (is_training and self.training and not self.by_idx[i].lock) for i in idxs)
+
+    def _fusion_plan(self, is_training: bool, first: int, last: int):
+        """layer index -> fused launch that replaces the layer (None: covered by a later entry).  Groups of layers whose
+        intermediates have a single consumer and whose batch norms are in inference mode in this pass: conv1+conv2, the
+        first residual block (conv3+conv4), the mask head (conv80+81+82) -- bf16 path only."""
+        plan = {}
+        if self.dtype == "fp8" and self.fp8_ready:
+            return plan
+        if first <= 1 and last >= 2 and self._can_fuse_first_two(is_training):
+            plan[1], plan[2] = None, self._forward_first_two
+        if self.fuse_blocks and not getattr(self, "plan_only", False):
+            l2, l4 = self.by_idx[2], self.by_idx[4]
+            if (first <= 3 and last >= 4 and self._inference_mode((3, 4), is_training)
+                    and L.block32_fused_ok(self.B, l4.Ho, l4.Wo, l2.cout, 0, 0)):
+                plan[3], plan[4] = None, self._forward_block34
+            l80, l82 = self.by_idx[80], self.by_idx[82]
+            if (first <= 80 and last >= 82 and self._inference_mode((80, 81, 82), is_training) and l82.cout == 9
+                    and L.block32_fused_ok(self.B, l82.Ho, l82.Wo, self.by_idx[l80.src].cout, self.by_idx[l80.src_up].cout, 1)):
+                plan[80], plan[81], plan[82] = None, None, self._forward_mask_head
+        return plan
 
     def _can_fuse_first_two(self, is_training: bool) -> bool:
         """conv1 and conv2 both in inference mode (folded moving statistics), bf16 path, a size the fused kernel covers"""
         if not self.fuse_first_two or (self.dtype == "fp8" and self.fp8_ready):
             return False
-        l1, l2 = self.by_idx[1], self.by_idx[2]
-        if self.training and not (l1.lock and l2.lock):
+        if not self._inference_mode((1, 2), is_training):
             return False            # (a trainable conv1 / conv2 needs its own output -- and its batch statistics)
         return L.conv12_fused_ok(self.B, self.S, self.S)
 

@@ -140,6 +140,19 @@ int disyolo_conv12_fused_fwd(const float* images, const float* w1_hwio, const fl
                              const void* w2_packed, const float* scale2, const float* shift2, void* y_bf16, int B, int H,
                              int W, float alpha, void* stream);
 
+/* The two HBM-bound [1x1 -> 32] -> [3x3 32 -> 64] chains of the half-resolution maps in one launch each, batch norms in
+ * inference mode (folded scale / shift, leaky alpha); the 32- and 64-channel intermediates stay on chip:
+ *   post 0  (C0 = 64, C1 = 0): y bf16 [B,H,W,64] = leaky(bnB(conv3x3(leaky(bnA(conv1x1(x0)))))) + x0 -- the first residual
+ *           block, yolo/yolo3_net_pos.py:172-189;
+ *   post 1  (C0 = 64, C1 = 32): y f32 [B,H,W,9] = conv1x1(leaky(bnB(conv3x3(leaky(bnA(conv1x1([x0, up2(x1)]))))))) + biasC -- the
+ *           mask head, yolo/yolo3_net_pos.py:455-476; x1 bf16 [B,H/2,W/2,32] is read at (y/2, x/2).
+ * x0 bf16 NHWC; wA packed [32][C0+C1], wB packed [64][9*32], wC packed [9][64] (pack_weights).  _ok: 1 when covered
+ * (those two shapes, H a multiple of 8, W of 16). */
+int disyolo_block32_fused_ok(int B, int H, int W, int C0, int C1, int post);
+int disyolo_block32_fused_fwd(const void* x0, const void* x1, int C0, int C1, const void* wA, const float* scaleA,
+                              const float* shiftA, const void* wB, const float* scaleB, const float* shiftB, int post,
+                              const void* wC, const float* biasC, void* y, int B, int H, int W, float alpha, void* stream);
+
 /* weight gradient (TF autodiff of tf.nn.conv2d wrt filters; train_yolo3_mask.py:55):
  * dw[kh,kw,ci,co] (f32 HWIO, overwritten) = sum_m xcol[m,(kh,kw,ci)] * dy[m,co].
  * Uses d->x0/x1 (the layer input, same gather as forward) and `dy` bf16 [B*Ho*Wo, dy_ld]

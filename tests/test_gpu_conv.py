@@ -374,6 +374,73 @@ def test_conv12_fused_matches_the_two_layers(dev, B, S):
     assert float((y.float() - y2.float()).abs().max()) <= 2.0 ** -6 * float(y2.float().abs().max())
 
 
+def _block32_operands(B, H, W, C1, seed):
+    g = torch.Generator().manual_seed(seed)
+    x0 = bf16r(torch.randn(B, H, W, 64, generator=g))
+    x1 = bf16r(torch.randn(B, H // 2, W // 2, C1, generator=g)) if C1 else None
+    wA = bf16r(torch.randn(1, 1, 64 + C1, 32, generator=g) / 8)
+    wB = bf16r(torch.randn(3, 3, 32, 64, generator=g) / 17)
+    scA, shA = (torch.rand(32, generator=g) + 0.5), torch.randn(32, generator=g) * 0.2
+    scB, shB = (torch.rand(64, generator=g) + 0.5), torch.randn(64, generator=g) * 0.2
+    return x0, x1, wA, wB, scA, shA, scB, shB
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 24, 48), (3, 8, 16), (1, 40, 16)])
+def test_block32_fused_residual_block(dev, B, H, W):
+    """[1x1 64 -> 32] -> [3x3 32 -> 64] + residual in one launch: against the f64 chain with the intermediate rounded to
+    bf16 where the unfused path stores it, and against the two unfused kernels on the same operands (same products, the
+    f32 sums in a different order: a bf16 rounding flips now and then)"""
+    x0, _, wA, wB, scA, shA, scB, shB = _block32_operands(B, H, W, 0, H + W + B)
+    assert L.block32_fused_ok(B, H, W, 64, 0, 0)
+    a3 = bf16r(O.leaky_relu(O.conv2d_same(x0, wA, 1) * scA.double() + shA.double(), 0.1).float())
+    want = O.leaky_relu(O.conv2d_same(a3, wB, 1) * scB.double() + shB.double(), 0.1) + x0
+    xd = x0.to(torch.bfloat16).to(dev)
+    wAp, wBp = pack_ref(wA).to(torch.bfloat16).to(dev), pack_ref(wB).to(torch.bfloat16).to(dev)
+    y = torch.full((B, H, W, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    L.block32_fused_fwd(xd, None, wAp, scA.to(dev), shA.to(dev), wBp, scB.to(dev), shB.to(dev), y, post=0, alpha=0.1)
+    torch.cuda.synchronize()
+    check(y, want, 2.0 ** -7, 3e-3)
+    y3 = torch.empty(B, H, W, 32, dtype=torch.bfloat16, device=dev)
+    L.conv2d_fwd(L.make_conv_desc(xd, wAp, y3, 1, 1, scale=scA.to(dev), shift=shA.to(dev), leaky=True))
+    y4 = torch.empty_like(y)
+    L.conv2d_fwd(L.make_conv_desc(y3, wBp, y4, 3, 1, scale=scB.to(dev), shift=shB.to(dev), residual=xd, leaky=True))
+    torch.cuda.synchronize()
+    same = float((y.view(torch.int16) == y4.view(torch.int16)).float().mean())
+    assert same > 0.97, same
+    assert float((y.float() - y4.float()).abs().max()) <= 2.0 ** -6 * float(y4.float().abs().max())
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 24, 48), (3, 8, 16)])
+def test_block32_fused_mask_head(dev, B, H, W):
+    """[1x1 (64 + up2(32)) -> 32] -> [3x3 32 -> 64] -> [1x1 64 -> 9] + bias in one launch, f32 out"""
+    x0, x1, wA, wB, scA, shA, scB, shB = _block32_operands(B, H, W, 32, H + W + B + 1)
+    g = torch.Generator().manual_seed(99)
+    wC = bf16r(torch.randn(1, 1, 64, 9, generator=g) / 8)
+    bC = torch.randn(9, generator=g) * 0.3
+    assert L.block32_fused_ok(B, H, W, 64, 32, 1)
+    up = x1.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    xin = torch.cat([x0, up], dim=3)
+    a80 = bf16r(O.leaky_relu(O.conv2d_same(xin, wA, 1) * scA.double() + shA.double(), 0.1).float())
+    a81 = bf16r(O.leaky_relu(O.conv2d_same(a80, wB, 1) * scB.double() + shB.double(), 0.1).float())
+    want = O.conv2d_same(a81, wC, 1) + bC.double()
+    x0d, x1d = x0.to(torch.bfloat16).to(dev), x1.to(torch.bfloat16).to(dev)
+    wAp, wBp, wCp = (pack_ref(w).to(torch.bfloat16).to(dev) for w in (wA, wB, wC))
+    y = torch.full((B, H, W, 9), float("nan"), dtype=torch.float32, device=dev)
+    L.block32_fused_fwd(x0d, x1d, wAp, scA.to(dev), shA.to(dev), wBp, scB.to(dev), shB.to(dev), y, post=1, wC=wCp, biasC=bC.to(dev),
+                        alpha=0.1)
+    torch.cuda.synchronize()
+    check(y, want, 2.0 ** -7, 2e-2)     # (a flipped bf16 rounding of act80 / act81 moves a sum of 64 products by ~1e-2)
+    y80 = torch.empty(B, H, W, 32, dtype=torch.bfloat16, device=dev)
+    L.conv2d_fwd(L.make_conv_desc(x0d, wAp, y80, 1, 1, x1=x1d, scale=scA.to(dev), shift=shA.to(dev), leaky=True))
+    y81 = torch.empty(B, H, W, 64, dtype=torch.bfloat16, device=dev)
+    L.conv2d_fwd(L.make_conv_desc(y80, wBp, y81, 3, 1, scale=scB.to(dev), shift=shB.to(dev), leaky=True))
+    y82 = torch.empty_like(y)
+    L.conv2d_fwd(L.make_conv_desc(y81, wCp, y82, 1, 1, shift=bC.to(dev), out_f32=True))
+    torch.cuda.synchronize()
+    assert float((y - y82).abs().max()) <= 2e-2 * max(1.0, float(y82.abs().max()))
+    assert float(((y - y82).abs() <= 1e-5 * (1 + y82.abs())).float().mean()) > 0.9
+
+
 def test_pack_weights(dev):
     g = torch.Generator().manual_seed(5)
     for k, cin, cout, pad in ((3, 64, 128, 128), (1, 96, 24, 32), (3, 32, 9, 32)):

@@ -110,7 +110,7 @@ def test_evaluation_matches_oracle_val_test(dev):
 def test_train_step_matches_oracle(dev, stage):
     B, S = 2, 64
     net = make_net(dev, True, stage, B=B, S=S, seed=1)
-    net.fuse_first_two = False      # the per-layer comparison below reads act1, which the fused launch never writes
+    net.fuse_first_two = net.fuse_blocks = False      # the per-layer comparison below reads act1 / act3, which the fused launches never write
     b = O.synthetic_batch(B, S, seed=11)
     rng = np.random.RandomState(0)
     perm_det = np.stack([rng.permutation(cfg.MAX_DETECTION) for _ in range(B)]).astype(np.int32)

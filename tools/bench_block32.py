@@ -1,0 +1,48 @@
+"""The fused [1x1 -> 32] -> [3x3 32 -> 64] launches against the separate kernels (GPU box): python tools/bench_block32.py [B] [S]
+S = the map size (288 for the 576^2 network)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import disyolo_amd
+from disyolo_amd import lib as L
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 288
+dev = torch.device("cuda:0")
+bf = torch.bfloat16
+x0 = torch.randn(B, S, S, 64, device=dev).to(bf)
+x1 = torch.randn(B, S // 2, S // 2, 32, device=dev).to(bf)
+wA0 = (torch.randn(32, 64, device=dev) / 8).to(bf)
+wA1 = (torch.randn(32, 96, device=dev) / 10).to(bf)
+wB = (torch.randn(64, 288, device=dev) / 17).to(bf)
+wC = (torch.randn(9, 64, device=dev) / 8).to(bf)
+scA, shA = torch.rand(32, device=dev) + 0.5, torch.randn(32, device=dev) * 0.2
+scB, shB = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.2
+bC = torch.randn(9, device=dev)
+y3 = torch.empty(B, S, S, 32, dtype=bf, device=dev)
+y4 = torch.empty(B, S, S, 64, dtype=bf, device=dev)
+y9 = torch.empty(B, S, S, 9, dtype=torch.float32, device=dev)
+flush = torch.empty(600 << 20, dtype=torch.uint8, device=dev)
+tune = {"3": (21, 3, 6), "4": (20, 2, 0x202), "80": (21, 4), "82": (21, 4)}
+def timeit(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    tot = 0.0
+    for _ in range(n):
+        flush.fill_(1)                      # evict the Infinity Cache: these layers run on cold data in the step
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record(); torch.cuda.synchronize()
+        tot += s.elapsed_time(e)
+    return tot / n * 1e3
+def best(mk, tiles):
+    return min(timeit(lambda d=mk(t): L.conv2d_fwd(d)) for t in tiles)
+t3 = best(lambda t: L.make_conv_desc(x0, wA0, y3, 1, 1, scale=scA, shift=shA, leaky=True, tile=t), (21, 6, 0x206))
+t4 = best(lambda t: L.make_conv_desc(y3, wB, y4, 3, 1, scale=scB, shift=shB, residual=x0, leaky=True, tile=t), (20, 2, 0x202))
+tf = timeit(lambda: L.block32_fused_fwd(x0, None, wA0, scA, shA, wB, scB, shB, y4, post=0))
+mb = B * S * S * 256 / 1e6
+print("B=%d %d^2 residual block: 1x1 %.1f us + 3x3 %.1f us = %.1f us; fused %.1f us (%.0f MB -> %.2f TB/s)" % (B, S, t3, t4, t3 + t4, tf, mb, mb / tf))
+t80 = best(lambda t: L.make_conv_desc(x0, wA1, y3, 1, 1, x1=x1, scale=scA, shift=shA, leaky=True, tile=t), (21, 4, 0x204))
+t81 = best(lambda t: L.make_conv_desc(y3, wB, y4, 3, 1, scale=scB, shift=shB, leaky=True, tile=t), (20, 2, 0x202))
+t82 = best(lambda t: L.make_conv_desc(y4, wC, y9, 1, 1, shift=bC, out_f32=True, tile=t), (21, 4, 0x204))
+tf = timeit(lambda: L.block32_fused_fwd(x0, x1, wA1, scA, shA, wB, scB, shB, y9, post=1, wC=wC, biasC=bC))
+mb = (B * S * S * (128 + 36) + B * (S // 2) ** 2 * 64) / 1e6
+print("B=%d %d^2 mask head: %.1f + %.1f + %.1f = %.1f us; fused %.1f us (%.0f MB -> %.2f TB/s)" % (B, S, t80, t81, t82, t80 + t81 + t82, tf, mb, mb / tf))
