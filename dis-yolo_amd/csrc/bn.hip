@@ -64,6 +64,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* stats, in
                                                           const float* gamma, const float* beta, float* mm, float* mv,
                                                           float decay, float eps, float* scale, float* shift,
                                                           float* mean_out, float* rstd_out) {
+  // the per-channel operands of the writers are fetched BEFORE the reduction: the kernel is two dependent memory round
+  // trips otherwise (partial rows, then gamma / beta / moving statistics), and it sits on the step's critical chain
+  const int c0 = blockIdx.x * FIN_CPB + threadIdx.x;
+  const bool writer = threadIdx.x < FIN_CPB && c0 < C;
+  const float g0 = writer ? gamma[c0] : 0.f, b0 = writer ? beta[c0] : 0.f;
+  const float mm0 = (writer && mm) ? mm[c0] : 0.f, mv0 = (writer && mv) ? mv[c0] : 0.f;
   double r[2];
   int c;
   if (!block_sum_partials<2>(stats, rows, C, r, &c)) return;
@@ -72,13 +78,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* stats, in
   if (var < 0.0) var = 0.0;
   const float meanf = (float)mean, varf = (float)var;
   const float rstd = 1.0f / sqrtf(varf + eps);
-  const float sc = gamma[c] * rstd;
+  const float sc = g0 * rstd;
   scale[c] = sc;
-  shift[c] = beta[c] - meanf * sc;
+  shift[c] = b0 - meanf * sc;
   if (mean_out) mean_out[c] = meanf;
   if (rstd_out) rstd_out[c] = rstd;
-  if (mm) mm[c] = mm[c] * decay + meanf * (1.0f - decay);
-  if (mv) mv[c] = mv[c] * decay + varf * (1.0f - decay);
+  if (mm) mm[c] = mm0 * decay + meanf * (1.0f - decay);
+  if (mv) mv[c] = mv0 * decay + varf * (1.0f - decay);
 }
 
 __global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mm, const float* mv, float eps,
@@ -212,15 +218,18 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part,
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part, int rows, int C, double inv_count,
                                                               const float* scale, const float* mean, const float* rstd,
                                                               float* dgamma, float* dbeta, float* cA, float* cC) {
+  const int c0 = blockIdx.x * FIN_CPB + threadIdx.x;   // (operands first, as in bn_finalize_kernel)
+  const bool writer = threadIdx.x < FIN_CPB && c0 < C;
+  const float sc0 = writer ? scale[c0] : 0.f, rs0 = writer ? rstd[c0] : 0.f, mean0 = writer ? mean[c0] : 0.f;
   double r[2];
   int c;
   if (!block_sum_partials<2>(part, rows, C, r, &c)) return;
   dbeta[c] = (float)r[0];
   dgamma[c] = (float)r[1];
   const float c1 = (float)(r[0] * inv_count), c2 = (float)(r[1] * inv_count);
-  const float A = scale[c] * rstd[c] * c2;
+  const float A = sc0 * rs0 * c2;
   cA[c] = A;
-  cC[c] = mean[c] * A - scale[c] * c1;
+  cC[c] = mean0 * A - sc0 * c1;
 }
 
 // ---- cross-rank batch statistics (SyncBN option of the data-parallel step) --------------

@@ -24,14 +24,13 @@ net.autotune()
 net.use_side_lane = False
 P = 7
 ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in net.layers] for _ in range(P)]
-fused12 = net._can_fuse_first_two(False)      # conv1 + conv2 in one launch: timed under layer 2, layer 1 shows 0
+plan = net._fusion_plan(False, 1, 82)          # fused launches: timed under the group's last layer, the others show 0
 for p in range(P):
     for i, l in enumerate(net.layers):
         ev[p][i][0].record()
-        if fused12 and l.idx == 1:
-            pass
-        elif fused12 and l.idx == 2:
-            net._forward_first_two()
+        if l.idx in plan:
+            if plan[l.idx] is not None:
+                plan[l.idx]()
         else:
             net._forward_layer(l, False)
         ev[p][i][1].record()
