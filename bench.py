@@ -226,6 +226,18 @@ def secondary_measurements(args, dev):
                                "conv_tiles": d["config"].get("conv_tiles"), "process": "child"}
     except Exception as e:   # a secondary line must never cost the headline
         out["train_stage2"] = {"error": repr(e)[:200]}
+    # the same stage-1 workload with the locked backbone batched over two steps (an option of the training loop, not the
+    # headline: every step still trains on its own batch and every image passes every layer exactly once)
+    if args.stage == 1 and args.dtype == "bf16":
+        try:
+            d = child(["--stage", "1", "--batch", str(args.batch), "--pair"])
+            out["train_stage1_backbone_pair"] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
+                                                 "ms_per_step": d["ms_per_step"], "steps": d["steps"], "repeats": d.get("repeats"),
+                                                 "what": d["config"].get("backbone_pair"),
+                                                 "loss_first": d["config"].get("loss_first"), "loss_last": d["config"].get("loss_last"),
+                                                 "conv_tiles": d["config"].get("conv_tiles"), "process": "child"}
+        except Exception as e:
+            out["train_stage1_backbone_pair"] = {"error": repr(e)[:200]}
     # BASELINE.json configs[4] at its per-GPU size: 832x832, 4 images per GPU, stage 1, the locked backbone in OCP e4m3
     # (and the same step in bf16 beside it: the non-scaled fp8 MFMA runs at the bf16 rate, fp8 can only win on bytes)
     for key, dt in (("train_832_fp8", "fp8"), ("train_832_bf16", "bf16")):
@@ -296,6 +308,9 @@ def main():
                          "table profiles/tune_<workload>.json when there is one for this workload (the run is then "
                          "bit-reproducible box to box and its losses are a regression canary), else tune live; "
                          "'none': always tune live")
+    ap.add_argument("--pair", action="store_true",
+                    help="stage 1: the locked backbone runs once per TWO batches at batch size 2B (YOLONet backbone_pair), "
+                         "the trainable part steps through the halves; an even number of steps, each on its own batch")
     ap.add_argument("--poison", action="store_true",
                     help="self-test of the loss canary: a NaN is written into one trainable weight before the timed "
                          "regions; the run must then FAIL (exit code 3, an \"error\" field, no throughput)")
@@ -333,17 +348,24 @@ def main():
     B, S = args.batch, args.size
     if args.task == "infer":
         return bench_infer(args, dev, world, rank)
-    net = YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=args.stage, seed=0, dtype=args.dtype)
+    if args.pair:
+        args.warmup += args.warmup % 2       # (an even number of untimed steps: the timed regions start on an even step)
+        if args.stage != 1 or use_dp or args.steps % 2 or args.mode not in ("auto", "program"):
+            raise SystemExit("--pair needs --stage 1, one GPU, the list executor and an even --steps")
+    net = YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=args.stage, seed=0, dtype=args.dtype,
+                  backbone_pair=args.pair)
     if use_dp:
         from disyolo_amd.dp import enable_data_parallel
         enable_data_parallel(net, sync_bn=args.sync_bn)
     batch = synthetic_batch(B, S, seed=1234 + rank)
     net.set_batch(batch)           # inputs resident in HBM from here on
+    if args.pair:
+        net.set_batch(synthetic_batch(B, S, seed=4321 + rank), 1)     # the odd steps' batch
     if args.dtype == "fp8":
         net.calibrate_fp8()        # static per-tensor scales (setup, outside the timed region)
     torch.manual_seed(1234 + rank)
     gen = None                     # default CUDA generator
-    workload = "train_B%d_%d_stage%d%s" % (B, S, args.stage, "" if args.dtype == "bf16" else "_fp8")
+    workload = "train_B%d_%d_stage%d%s%s" % (B, S, args.stage, "" if args.dtype == "bf16" else "_fp8", "_pair" if args.pair else "")
     cache = tune_cache_path(args, workload)
     if args.autotune == "on":
         t_tune = time.perf_counter()
@@ -442,6 +464,9 @@ def main():
                        "conv_tiles": ("table %s" % os.path.relpath(cache, ROOT)) if cache else
                                      ("autotuned in-sequence at setup" if args.autotune == "on" else "launcher heuristic"),
                        "backbone_pipeline": bool(args.stage == 1 and mode == "program" and args.pipeline == "on"),
+                       "backbone_pair": ("locked conv1-52 run once per two batches at 2B; every batch passes every layer once; "
+                                         "steps alternate (backbone + trainable part | trainable part), ms_per_step is their mean")
+                                        if args.pair else False,
                        "loss_first": round(loss_trace[0], 4) if np.isfinite(loss_trace[0]) else None,
                        "loss_last": round(loss, 4) if np.isfinite(loss) else None,
                        "final_total_loss": round(loss, 4) if np.isfinite(loss) else None,

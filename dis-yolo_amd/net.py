@@ -119,7 +119,8 @@ def var_name(i: int, leaf: str) -> str:
 class YOLONet(object):
     def __init__(self, training: bool = False, device=None, image_size: Optional[int] = None,
                  batch_size: Optional[int] = None, stage: int = 1, lock: Optional[Dict[int, bool]] = None,
-                 seed: int = 0, xavier_locked: bool = True, plan_only: bool = False, dtype: str = "bf16"):
+                 seed: int = 0, xavier_locked: bool = True, plan_only: bool = False, dtype: str = "bf16",
+                 backbone_pair: bool = False):
         # 1. parameters (yolo/yolo3_net_pos.py:15-38)
         self.batchsize = int(batch_size if batch_size is not None else cfg.BATCH_SIZE)
         self.classes = cfg.CLASSES
@@ -192,7 +193,21 @@ class YOLONet(object):
             print("disyolo: DISYOLO_EXP_SKIP_WGRAD is set -- weight gradients are NOT computed (timing experiment)", file=sys.stderr)
         # weight gradients of the last layers of the backward pass stay on the main lane (tuned below)
         self.tail_on_main = int(os.environ.get("DISYOLO_TAIL_MAIN", "0"))
+        # backbone_pair (stage 1): the locked backbone -- whose output depends on nothing a step updates -- runs ONCE
+        # per TWO batches at batch size 2B (a 576^2 B = 8 layer is a one-round grid: 169 us per image at B = 8, 137 at
+        # B = 16), the trainable part steps through the two halves one after the other.  Every image still passes
+        # every layer exactly once; the weights after N steps are those of N plain steps up to the f32 summation order
+        # of the differently tiled backbone kernels.  set_batch(batch, half), build_program(pair=True).
+        self.pair = bool(backbone_pair)
+        self._half = 0
+        self._pair_P = 0
         self._init_params(seed, xavier_locked)
+        if self.pair:
+            if not self.training or self.dtype != "bf16" or self.plan_only:
+                raise L.DisyoloError("backbone_pair needs a bf16 training net")
+            self._pair_P = self._backbone_prefix()
+            if self._pair_P < 2:
+                raise L.DisyoloError("backbone_pair needs a locked layer prefix (stage 1)")
         if not self.plan_only:
             self._plan(self.batchsize, self.image_size)
 
@@ -317,7 +332,7 @@ class YOLONet(object):
         for (B, S): nothing is allocated inside forward / train_step."""
         dev = self.device
         self.B, self.S = B, S
-        self.images = torch.zeros(B, S, S, 3, dtype=F32, device=dev)
+        self.images = torch.zeros(2 * B if self.pair else B, S, S, 3, dtype=F32, device=dev)
         spatial = {0: (S, S)}
         # which activations need a gradient: any trainable layer at or upstream of a consumer
         for l in self.layers:
@@ -348,8 +363,9 @@ class YOLONet(object):
         # one large region fares better than eighty medium ones
         use_arena = os.environ.get("DISYOLO_ARENA", "1") != "0"
         need = 0
+        batch_of = lambda l: 2 * B if (self.pair and l.idx <= self._pair_P) else B
         for l in self.layers:
-            n = B * l.Ho * l.Wo * l.cout
+            n = batch_of(l) * l.Ho * l.Wo * l.cout
             tb = self.training and (not l.lock) and l.kind != "lin"
             need += ((n * (4 if l.kind == "lin" else 2) + 255) // 256) * 256 * (2 if tb else 1)
         self._act_arena = torch.zeros(need, dtype=torch.uint8, device=dev) if use_arena else None
@@ -369,7 +385,7 @@ class YOLONet(object):
             if l.kind == "lin":
                 l.act = zeros4(B, l.Ho, l.Wo, l.cout, F32)
             else:
-                l.act = zeros4(B, l.Ho, l.Wo, l.cout, BF16)
+                l.act = zeros4(batch_of(l), l.Ho, l.Wo, l.cout, BF16)
                 l.raw = zeros4(B, l.Ho, l.Wo, l.cout, BF16) if train_bn else None
             if l.idx > 1:
                 K = l.k * l.k * l.cin
@@ -416,6 +432,12 @@ class YOLONet(object):
             self.perm_gt = torch.arange(G, dtype=torch.int32, device=dev).repeat(B, 1).contiguous()
             self.rois = torch.zeros(B, L.ROI_MAX, L.ROI_W, dtype=torch.int32, device=dev)
             self.roi_count = torch.zeros(B, dtype=torch.int32, device=dev)
+            self._in_sets = None
+            if self.pair:     # the per-batch inputs of the trainable part, once per half
+                names = ("labels", "true_boxes", "true_masks", "perm_det", "perm_gt", "clip_window")
+                first = {n: getattr(self, n) for n in names}
+                second = {n: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for n, v in first.items()}
+                self._in_sets = [first, second]
             self.losses = torch.zeros(8, dtype=F32, device=dev)
             self.mask_loss = torch.zeros(1, dtype=F32, device=dev)
             self.reg_loss = torch.zeros(1, dtype=F32, device=dev)
@@ -496,9 +518,9 @@ class YOLONet(object):
         for l in self.layers:
             if l.idx == 1:
                 continue
-            x0 = self.by_idx[l.src].act
-            x1 = self.by_idx[l.src_up].act if l.src_up is not None else None
-            res = self.by_idx[l.shortcut].act if l.shortcut is not None else None
+            x0 = self._input_of(l, l.src)
+            x1 = self._input_of(l, l.src_up) if l.src_up is not None else None
+            res = self._input_of(l, l.shortcut) if l.shortcut is not None else None
             train_bn = self.training and (not l.lock) and l.kind != "lin"
             if l.kind == "lin":
                 l.desc = L.make_conv_desc(x0, l.wp, l.act, l.k, l.stride, x1=x1, shift=l.bias, out_f32=True)
@@ -513,6 +535,14 @@ class YOLONet(object):
                                           residual=res, leaky=True, alpha=cfg.ALPHA)
             if self.training and not l.lock:
                 l.wgrad_desc = L.make_conv_desc(x0, l.wp, l.act, l.k, l.stride, x1=x1)
+
+    def _input_of(self, l, src: int) -> torch.Tensor:
+        """activation of layer ``src`` as layer ``l`` reads it (backbone_pair: a trainable layer sees the current half of
+        a backbone output)"""
+        a = self.by_idx[src].act
+        if self.pair and src <= self._pair_P < l.idx:
+            return a[self._half * self.B:(self._half + 1) * self.B]
+        return a
 
     # ---- cross-step software pipeline of the locked backbone (stage 1) -------------------
     def _backbone_prefix(self) -> int:
@@ -672,7 +702,7 @@ class YOLONet(object):
             return
         train_bn = is_training and self.training and (not l.lock) and l.kind != "lin"
         M = B * l.Ho * l.Wo
-        res = self.by_idx[l.shortcut].act if l.shortcut is not None else None
+        res = self._input_of(l, l.shortcut) if l.shortcut is not None else None
         if l.idx == 1:
             if train_bn:
                 L.conv_first_fwd(self.images, l.w, self._ones32, self._zeros32, l.raw, alpha=1.0)
@@ -694,8 +724,8 @@ class YOLONet(object):
             if self.training and not l.lock:
                 # a training-mode plan evaluated with is_training=False: moving statistics
                 L.bn_fold(l.gamma, l.beta, l.mm, l.mv, cfg.BN_EPSILON, l.scale, l.shift)
-                d = L.make_conv_desc(self.by_idx[l.src].act, l.wp, l.act, l.k, l.stride,
-                                     x1=self.by_idx[l.src_up].act if l.src_up is not None else None,
+                d = L.make_conv_desc(self._input_of(l, l.src), l.wp, l.act, l.k, l.stride,
+                                     x1=self._input_of(l, l.src_up) if l.src_up is not None else None,
                                      scale=l.scale, shift=l.shift, residual=res, leaky=True, alpha=cfg.ALPHA)
                 L.conv2d_fwd(d)
             else:
@@ -744,13 +774,21 @@ class YOLONet(object):
                  self.anchors.reshape(-1), self.clip_window, float(det_thresh), cfg.IOU_THRESHOLD, cfg.MAX_DETECTION,
                  self.detections, self.det_count, self.ws_det)
 
-    def _set_inputs(self, images, clip_window) -> None:
+    def _use_half(self, h: int) -> None:
+        """backbone_pair: the trainable part reads half ``h`` of the backbone outputs and the inputs of that batch"""
+        self._half = int(h)
+        for n, v in self._in_sets[self._half].items():
+            setattr(self, n, v)
+        self._build_descs()
+
+    def _set_inputs(self, images, clip_window, half: int = 0) -> None:
         images = torch.as_tensor(images)
         if tuple(images.shape) != (self.B, self.S, self.S, 3):
             raise ValueError("images must be [%d,%d,%d,3] NHWC (batch size and image size are baked into the plan, "
                              "as in the reference: yolo/yolo3_net_pos.py:17)" % (self.B, self.S, self.S))
-        self.images.copy_(images.to(self.device, F32, non_blocking=True))
-        self.clip_window.copy_(torch.as_tensor(clip_window).to(self.device, F32).reshape(self.B, 4))
+        cw = self.clip_window if not self.pair else self._in_sets[half]["clip_window"]
+        self.images[half * self.B:(half + 1) * self.B].copy_(images.to(self.device, F32, non_blocking=True))
+        cw.copy_(torch.as_tensor(clip_window).to(self.device, F32).reshape(self.B, 4))
 
     def forward(self, images, clip_window, det_thresh=cfg.OBJ_THRESHOLD, is_training: bool = False):
         """``sess.run(net.logits)``: returns (predictions, detections, mask_pos) with
@@ -825,18 +863,22 @@ class YOLONet(object):
         return self.detections, self.det_count, self.masks, self.keep
 
     # ------------------------------------------------------------------ training
-    def set_batch(self, batch: Dict) -> None:
-        """feed_dict of Solver.train (train_yolo3_mask.py:146-149)."""
-        self._set_inputs(batch["images"], batch["clip_window"])
+    def set_batch(self, batch: Dict, half: int = 0) -> None:
+        """feed_dict of Solver.train (train_yolo3_mask.py:146-149).  backbone_pair: ``half`` 0 = the batch of the next
+        even step, 1 = of the odd step after it; both are set before the even step runs."""
+        if half and not self.pair:
+            raise L.DisyoloError("set_batch(half=1) on a net built without backbone_pair")
+        self._set_inputs(batch["images"], batch["clip_window"], half)
         dev = self.device
-        for t, key in zip(self.labels, ("yolo3", "yolo2", "yolo1")):
+        tgt = self._in_sets[half] if self.pair else {n: getattr(self, n) for n in ("labels", "true_boxes", "true_masks", "perm_det", "perm_gt")}
+        for t, key in zip(tgt["labels"], ("yolo3", "yolo2", "yolo1")):
             t.copy_(torch.as_tensor(batch[key]).to(dev, F32).reshape(t.shape))
-        self.true_boxes.copy_(torch.as_tensor(batch["true_boxes"]).to(dev, F32).reshape(self.true_boxes.shape))
+        tgt["true_boxes"].copy_(torch.as_tensor(batch["true_boxes"]).to(dev, F32).reshape(tgt["true_boxes"].shape))
         tm = torch.as_tensor(batch["true_masks"])
-        self.true_masks.copy_(tm.to(dev).to(torch.uint8).reshape(self.true_masks.shape))
+        tgt["true_masks"].copy_(tm.to(dev).to(torch.uint8).reshape(tgt["true_masks"].shape))
         if batch.get("perm_det") is not None:
-            self.perm_det.copy_(torch.as_tensor(batch["perm_det"]).to(dev, torch.int32).reshape(self.perm_det.shape))
-            self.perm_gt.copy_(torch.as_tensor(batch["perm_gt"]).to(dev, torch.int32).reshape(self.perm_gt.shape))
+            tgt["perm_det"].copy_(torch.as_tensor(batch["perm_det"]).to(dev, torch.int32).reshape(tgt["perm_det"].shape))
+            tgt["perm_gt"].copy_(torch.as_tensor(batch["perm_gt"]).to(dev, torch.int32).reshape(tgt["perm_gt"].shape))
 
     def shuffle_rois(self, generator: Optional[torch.Generator] = None) -> None:
         """tf.random_shuffle of proposals / GT boxes (yolo/yolo3_net_pos.py:781-782), host-driven
@@ -1238,6 +1280,21 @@ class YOLONet(object):
         """
         if not self.training:
             raise L.DisyoloError("build_program on a YOLONet built with training=False")
+        if self.pair:
+            # two lists: the even step = the backbone on both batches + the trainable part on the first half, the odd
+            # step = the trainable part on the second half; run_program alternates
+            if graph or pipeline_backbone or self.dp is not None:
+                raise L.DisyoloError("backbone_pair uses the single-GPU list executor")
+            self._progs = []
+            for h in (0, 1):
+                self._use_half(h)
+                self._progs.append(self._record_step(det_thresh, None))
+            self._use_half(0)
+            self._parity = 0
+            self.ws.frozen = True
+            self.ws_aux.frozen = True
+            self._prog, self._prog_marks, self._bwd_end = self._progs[0]
+            return
         if pipeline_backbone:
             if graph:
                 raise L.DisyoloError("pipeline_backbone uses the list executor, not a hipGraph")
@@ -1292,6 +1349,8 @@ class YOLONet(object):
             if parity is not None:
                 self._use_parity(parity)
                 first = self._pipe_P + 1
+            if self.pair and self._half == 1:
+                first = self._pair_P + 1         # (the even step ran the backbone for this half too)
             self.compute_losses(det_thresh, first)
             if parity is not None:
                 # the next batch's backbone: lowest-priority lane, started once the trunk's forward
@@ -1361,10 +1420,24 @@ class YOLONet(object):
         if not self.training:
             raise L.DisyoloError("train_step on a YOLONet built with training=False")
         if batch is not None:
-            self.set_batch(batch)
+            if self.pair:
+                # (batch of this step, batch of the next one) before an even step; nothing before an odd one
+                if self._parity_now() != 0 or len(batch) != 2:
+                    raise L.DisyoloError("backbone_pair: pass the two batches of a step pair to the even step, None to the odd one")
+                self.set_batch(batch[0], 0)
+                self.set_batch(batch[1], 1)
+            else:
+                self.set_batch(batch)
         if self._prog is not None:
             self.run_program()
             return self.total_loss() if want_loss else None
+        if self.pair:
+            self.compute_losses(det_thresh, 1 if self._half == 0 else self._pair_P + 1)
+            self.backward(sweep=True)
+            self.optimizer_step()
+            loss = self.total_loss() if want_loss else None
+            self._use_half(1 - self._half)
+            return loss
         self.compute_losses(det_thresh)
         if self.dp is not None:
             self.dp.begin_step()
@@ -1377,6 +1450,10 @@ class YOLONet(object):
         # every term is the value for the weights BEFORE the update, like TF's fetch of total_loss
         # next to the train op (the l2 term comes out of the Adam sweep)
         return self.total_loss() if want_loss else None
+
+    def _parity_now(self) -> int:
+        """backbone_pair: 0 before an even step (which needs both batches set), 1 before an odd one"""
+        return self._parity if self._progs is not None else self._half
 
     def summaries(self) -> Dict[str, float]:
         """the 7 tf.summary scalars (yolo/yolo3_net_pos.py:62,743-747,860)."""

@@ -150,6 +150,8 @@ class Solver(object):
         net = self.net
         if self.use_program and net._prog is None:
             net.set_batch(self._feed_peek())
+            if getattr(net, "pair", False):
+                net.set_batch(self._pending, 1)      # (placeholder inputs while the two lists are recorded)
             net.build_program(det_thresh=cfg.OBJ_THRESHOLD)
         history = []
         for step in range(self.start_iter, self.max_iter + 1):
@@ -158,7 +160,12 @@ class Solver(object):
                 self.learning_rate = shown_lr
                 net.learning_rate = shown_lr
             load_timer.tic()
-            feed = self._next_feed()
+            if getattr(net, "pair", False):
+                # backbone_pair: the even step takes its own batch and the next one (the locked backbone runs on both),
+                # the odd step takes nothing
+                feed = (self._next_feed(), self._next_feed()) if net._parity_now() == 0 else None
+            else:
+                feed = self._next_feed()
             load_timer.toc()
             train_timer.tic()
             loss = float(net.train_step(feed, det_thresh=cfg.OBJ_THRESHOLD).cpu())

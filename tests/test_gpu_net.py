@@ -436,6 +436,33 @@ def test_pipelined_backbone_step_equals_plain_step(dev):
         assert torch.equal(plain.params[name], piped.params[name]), name
 
 
+@pytest.mark.parametrize("recorded", [False, True])
+def test_backbone_pair_steps_match_plain_steps(dev, recorded):
+    """Stage 1 with backbone_pair: the locked backbone runs once per two batches at batch size 2B, the trainable part steps
+    through the halves.  Four steps on four different batches against four plain steps: the same losses and the same
+    weights up to the f32 summation order of the backbone kernels (a different batch size may pick other tiles)."""
+    B, S = 2, 64
+    batches = [O.synthetic_batch(B, S, seed=70 + t) for t in range(5)]
+    plain = make_net(dev, True, 1, B=B, S=S, seed=8)
+    pair = YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=1, seed=8, backbone_pair=True)
+    pair.load_state_dict(plain.state_dict())
+    assert pair.by_idx[52].act.shape[0] == 2 * B and pair.by_idx[53].act.shape[0] == B
+    if recorded:
+        plain.build_program(det_thresh=0.1)
+        pair.build_program(det_thresh=0.1)
+    lp, lq = [], []
+    for t in range(4):
+        lp.append(float(plain.train_step(batches[t], det_thresh=0.1).cpu()))
+        lq.append(float(pair.train_step((batches[t], batches[t + 1]) if t % 2 == 0 else None, det_thresh=0.1).cpu()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(lq, lp, rtol=2e-3)
+    with pytest.raises(L.DisyoloError):
+        plain.set_batch(batches[0], 1)          # there is no second half in a plain net
+    for name in plain.params:
+        a, b = plain.params[name], pair.params[name]
+        assert float((a - b).abs().max()) <= 4.5e-4 + 1e-3 * float(a.abs().max()), name     # (Adam: |step| <= lr = 1e-4 each)
+
+
 def test_device_shuffle_produces_fresh_uniform_permutations(dev):
     B = 64
     pd = torch.zeros(B, 30, dtype=torch.int32, device=dev)

@@ -2,7 +2,7 @@
 """Tile tables bench.py loads by default (GPU box): the in-sequence autotuner with more passes than bench.py's
 setup run takes (median of 9 instead of 3), one table per workload, written to gpurun_out/ (copy them to profiles/).
 
-    python tools/make_tune_tables.py [train1] [train2] [infer] [train832] [train832fp8]
+    python tools/make_tune_tables.py [train1] [train2] [infer] [train832] [train832fp8] [train1pair]
 """
 import os
 import sys
@@ -32,9 +32,12 @@ for w in what:
         stage = 2 if w == "train2" else 1
         B, S = (4, 832) if "832" in w else (8, 576)
         dtype = "fp8" if w.endswith("fp8") else "bf16"
-        name = "tune_train_B%d_%d_stage%d%s.json" % (B, S, stage, "" if dtype == "bf16" else "_fp8")
-        net = YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=stage, seed=0, dtype=dtype)
+        pair = w.endswith("pair")
+        name = "tune_train_B%d_%d_stage%d%s%s.json" % (B, S, stage, "" if dtype == "bf16" else "_fp8", "_pair" if pair else "")
+        net = YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=stage, seed=0, dtype=dtype, backbone_pair=pair)
         net.set_batch(synthetic_batch(B, S, seed=1234))
+        if pair:
+            net.set_batch(synthetic_batch(B, S, seed=4321), 1)
         if dtype == "fp8":
             net.calibrate_fp8()
     path = os.path.join(OUT, name)
