@@ -57,6 +57,8 @@ _SIGS = {
     "disyolo_conv12_fused_ok": (C.c_int, [C.c_int] * 3),
     "disyolo_conv12_fused_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
     "disyolo_block32_fused_ok": (C.c_int, [C.c_int] * 6),
+    "disyolo_block64_fused_ok": (C.c_int, [C.c_int] * 4),
+    "disyolo_block64_fused_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "disyolo_block32_fused_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int] +
                                   [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
     "disyolo_conv2d_wgrad_workspace": (C.c_size_t, [C.POINTER(ConvDesc), C.c_int]),
@@ -533,6 +535,24 @@ def block32_fused_fwd(x0, x1, wA, scaleA, shiftA, wB, scaleB, shiftB, y, post=0,
         flops = 2.0 * M * (32 * (C0 + C1) + 64 * 288 + (64 * 9 if post else 0))
         nbytes = M * C0 * 2 + (M // 4) * C1 * 2 + (M * 36 if post else M * 128)
         TIMER.run("block32_kernel<%d,%d>" % (C0 + C1, post), flops, fn, float(nbytes))
+        return
+    fn()
+
+
+def block64_fused_ok(B: int, H: int, W: int, C0: int) -> bool:
+    return load().disyolo_block64_fused_ok(B, H, W, C0) == 1
+
+
+def block64_fused_fwd(x, wA, scaleA, shiftA, wB, scaleB, shiftB, y, alpha=0.1) -> None:
+    """a residual block of the 144^2 maps, [1x1 128 -> 64] -> [3x3 64 -> 128] + x with folded batch norms, in one launch"""
+    _need(x, torch.bfloat16, "x")
+    _need(y, torch.bfloat16, "y")
+    B, H, W, C0 = x.shape
+    fn = lambda: _check(load().disyolo_block64_fused_fwd(_p(x), _p(wA), _p(scaleA), _p(shiftA), _p(wB), _p(scaleB), _p(shiftB), _p(y),
+                                                         B, H, W, C0, alpha, _stream()), "block64_fused_fwd")
+    if TIMER is not None:
+        M = B * H * W
+        TIMER.run("block64_kernel", 2.0 * M * (64 * 128 + 128 * 576), fn, float(M * 512))
         return
     fn()
 

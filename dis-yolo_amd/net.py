@@ -647,6 +647,10 @@ class YOLONet(object):
         l2, l3, l4 = self.by_idx[2], self.by_idx[3], self.by_idx[4]
         L.block32_fused_fwd(l2.act, None, l3.wp, l3.scale, l3.shift, l4.wp, l4.scale, l4.shift, l4.act, post=0, alpha=cfg.ALPHA)
 
+    def _forward_block64(self, i3: int) -> None:
+        la, lb = self.by_idx[i3 - 1], self.by_idx[i3]
+        L.block64_fused_fwd(self.by_idx[la.src].act, la.wp, la.scale, la.shift, lb.wp, lb.scale, lb.shift, lb.act, alpha=cfg.ALPHA)
+
     def _forward_mask_head(self) -> None:
         l80, l81, l82 = self.by_idx[80], self.by_idx[81], self.by_idx[82]
         L.block32_fused_fwd(self.by_idx[l80.src].act, self.by_idx[l80.src_up].act, l80.wp, l80.scale, l80.shift, l81.wp, l81.scale,
@@ -681,6 +685,11 @@ class YOLONet(object):
             if (first <= 3 and last >= 4 and self._inference_mode((3, 4), is_training)
                     and L.block32_fused_ok(self.B, l4.Ho, l4.Wo, l2.cout, 0, 0)):
                 plan[3], plan[4] = None, self._forward_block34
+            for i3 in ((7, 9) if os.environ.get("DISYOLO_FUSE_B64", "1") != "0" else ()):   # the 144^2 residual blocks: conv6+7, conv8+9
+                lb = self.by_idx[i3]
+                if (first <= i3 - 1 and last >= i3 and self._inference_mode((i3 - 1, i3), is_training)
+                        and L.block64_fused_ok(self.B, lb.Ho, lb.Wo, self.by_idx[i3 - 2].cout)):
+                    plan[i3 - 1], plan[i3] = None, (lambda i3=i3: self._forward_block64(i3))
             l80, l82 = self.by_idx[80], self.by_idx[82]
             if (first <= 80 and last >= 82 and self._inference_mode((80, 81, 82), is_training) and l82.cout == 9
                     and L.block32_fused_ok(self.B, l82.Ho, l82.Wo, self.by_idx[l80.src].cout, self.by_idx[l80.src_up].cout, 1)):

@@ -153,6 +153,15 @@ int disyolo_block32_fused_fwd(const void* x0, const void* x1, int C0, int C1, co
                               const float* shiftA, const void* wB, const float* scaleB, const float* shiftB, int post,
                               const void* wC, const float* biasC, void* y, int B, int H, int W, float alpha, void* stream);
 
+/* A residual block of the quarter-resolution maps in one launch, batch norms in inference mode: y bf16 [B,H,W,128] =
+ * leaky(bnB(conv3x3(leaky(bnA(conv1x1(x)))))) + x with x bf16 [B,H,W,128], wA packed [64][128], wB packed [128][9*64]
+ * (yolo/yolo3_net_pos.py:194-211, conv6+7 and conv8+9); the 64-channel intermediate stays in LDS.  _ok: C0 == 128, H a
+ * multiple of 8, W of 16. */
+int disyolo_block64_fused_ok(int B, int H, int W, int C0);
+int disyolo_block64_fused_fwd(const void* x, const void* wA, const float* scaleA, const float* shiftA, const void* wB,
+                              const float* scaleB, const float* shiftB, void* y, int B, int H, int W, int C0, float alpha,
+                              void* stream);
+
 /* weight gradient (TF autodiff of tf.nn.conv2d wrt filters; train_yolo3_mask.py:55):
  * dw[kh,kw,ci,co] (f32 HWIO, overwritten) = sum_m xcol[m,(kh,kw,ci)] * dy[m,co].
  * Uses d->x0/x1 (the layer input, same gather as forward) and `dy` bf16 [B*Ho*Wo, dy_ld]

@@ -410,6 +410,35 @@ def test_block32_fused_residual_block(dev, B, H, W):
     assert float((y.float() - y4.float()).abs().max()) <= 2.0 ** -6 * float(y4.float().abs().max())
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 24, 48), (3, 8, 16), (1, 40, 16), (2, 128, 144)])
+def test_block64_fused_residual_block(dev, B, H, W):
+    """[1x1 128 -> 64] -> [3x3 64 -> 128] + residual in one launch (one persistent block per CU, input tile double-buffered;
+    2 x 128 x 144 = 288 patches: 32 blocks walk over two; 40 x 16 and 24 x 48 put a patch on every border)"""
+    g = torch.Generator().manual_seed(H + W + B + 7)
+    x0 = bf16r(torch.randn(B, H, W, 128, generator=g))
+    wA = bf16r(torch.randn(1, 1, 128, 64, generator=g) / 11)
+    wB = bf16r(torch.randn(3, 3, 64, 128, generator=g) / 24)
+    scA, shA = (torch.rand(64, generator=g) + 0.5), torch.randn(64, generator=g) * 0.2
+    scB, shB = (torch.rand(128, generator=g) + 0.5), torch.randn(128, generator=g) * 0.2
+    assert L.block64_fused_ok(B, H, W, 128) and not L.block64_fused_ok(B, H, W, 64)
+    am = bf16r(O.leaky_relu(O.conv2d_same(x0, wA, 1) * scA.double() + shA.double(), 0.1).float())
+    want = O.leaky_relu(O.conv2d_same(am, wB, 1) * scB.double() + shB.double(), 0.1) + x0
+    xd = x0.to(torch.bfloat16).to(dev)
+    wAp, wBp = pack_ref(wA).to(torch.bfloat16).to(dev), pack_ref(wB).to(torch.bfloat16).to(dev)
+    y = torch.full((B, H, W, 128), float("nan"), dtype=torch.bfloat16, device=dev)
+    L.block64_fused_fwd(xd, wAp, scA.to(dev), shA.to(dev), wBp, scB.to(dev), shB.to(dev), y, alpha=0.1)
+    torch.cuda.synchronize()
+    check(y, want, 2.0 ** -7, 3e-3)
+    ym = torch.empty(B, H, W, 64, dtype=torch.bfloat16, device=dev)
+    L.conv2d_fwd(L.make_conv_desc(xd, wAp, ym, 1, 1, scale=scA.to(dev), shift=shA.to(dev), leaky=True))
+    y2 = torch.empty_like(y)
+    L.conv2d_fwd(L.make_conv_desc(ym, wBp, y2, 3, 1, scale=scB.to(dev), shift=shB.to(dev), residual=xd, leaky=True))
+    torch.cuda.synchronize()
+    same = float((y.view(torch.int16) == y2.view(torch.int16)).float().mean())
+    assert same > 0.97, same
+    assert float((y.float() - y2.float()).abs().max()) <= 2.0 ** -6 * float(y2.float().abs().max())
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 24, 48), (3, 8, 16)])
 def test_block32_fused_mask_head(dev, B, H, W):
     """[1x1 (64 + up2(32)) -> 32] -> [3x3 32 -> 64] -> [1x1 64 -> 9] + bias in one launch, f32 out"""

@@ -46,3 +46,20 @@ t82 = best(lambda t: L.make_conv_desc(y4, wC, y9, 1, 1, shift=bC, out_f32=True, 
 tf = timeit(lambda: L.block32_fused_fwd(x0, x1, wA1, scA, shA, wB, scB, shB, y9, post=1, wC=wC, biasC=bC))
 mb = (B * S * S * (128 + 36) + B * (S // 2) ** 2 * 64) / 1e6
 print("B=%d %d^2 mask head: %.1f + %.1f + %.1f = %.1f us; fused %.1f us (%.0f MB -> %.2f TB/s)" % (B, S, t80, t81, t82, t80 + t81 + t82, tf, mb, mb / tf))
+
+# the 144^2 residual blocks (conv6+7, conv8+9): [1x1 128 -> 64] -> [3x3 64 -> 128] + residual
+S2 = S // 2
+xa = torch.randn(B, S2, S2, 128, device=dev).to(bf)
+wa = (torch.randn(64, 128, device=dev) / 11).to(bf)
+wb = (torch.randn(128, 576, device=dev) / 24).to(bf)
+sa, ha = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.2
+sb, hb = torch.rand(128, device=dev) + 0.5, torch.randn(128, device=dev) * 0.2
+ym = torch.empty(B, S2, S2, 64, dtype=bf, device=dev)
+yo = torch.empty(B, S2, S2, 128, dtype=bf, device=dev)
+t6 = best(lambda t: L.make_conv_desc(xa, wa, ym, 1, 1, scale=sa, shift=ha, leaky=True, tile=t), (21, 6, 0x206, 2))
+t7 = best(lambda t: L.make_conv_desc(ym, wb, yo, 3, 1, scale=sb, shift=hb, residual=xa, leaky=True, tile=t), (0, 16, 12, 2, 0x202, 3))
+tf = timeit(lambda: L.block64_fused_fwd(xa, wa, sa, ha, wb, sb, hb, yo))
+mb = B * S2 * S2 * 512 / 1e6
+gf = 2.0 * B * S2 * S2 * (64 * 128 + 128 * 576) / 1e9
+print("B=%d %d^2 residual block 128: 1x1 %.1f us + 3x3 %.1f us = %.1f us; fused %.1f us (%.0f MB -> %.2f TB/s, %.0f TFLOP/s)"
+      % (B, S2, t6, t7, t6 + t7, tf, mb, mb / tf, gf / tf * 1e3))
