@@ -41,6 +41,7 @@ struct ConvParams {
   int M, K, nk;
   unsigned bytes0, bytes1, bytesw;
   int tilesM, tilesN;
+  int xcd_n;                 // GEMM tiles: an XCD's run of tiles walks the pixel tiles of a few channel tiles (weights > input)
   int flags;
   float alpha;
 };
@@ -147,13 +148,23 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
   // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a
   // contiguous run of tiles, n-tile fastest, so the blocks that re-read one pixel panel
   // (and neighbouring halo rows) hit the same L2.  Bijective for any grid size.
+  // Every XCD then reads 1/8 of the pixels and ALL the weights: right while the input is the larger operand; where the
+  // weights are (the 18^2 layers: 9.4 MB of weights, 2.6 MB of input at B = 8) the run goes m-tile fastest instead --
+  // 1/8 of the weights and all the pixels per XCD (xcd_n, set by the launcher)
   int tile;
   {
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int mt = tile / p.tilesN, nt = tile - mt * p.tilesN;
+  int mt, nt;
+  if (p.xcd_n) {
+    nt = tile / p.tilesM;
+    mt = tile - nt * p.tilesM;
+  } else {
+    mt = tile / p.tilesN;
+    nt = tile - mt * p.tilesN;
+  }
   const int m0 = mt * BM, n0 = nt * BN;
 
   // ---- per-lane gather state.  DMA j of this wave fills LDS bytes
@@ -1700,6 +1711,10 @@ int launch_ks(const ConvParams& p, hipStream_t s) {
   q.tilesM = ceil_div(p.M, BM);
   q.tilesN = ceil_div(p.Cout, BN);
   q.nk = p.K / BK;
+  {
+    static const bool on = [] { const char* e = getenv("DISYOLO_XCD_N"); return !(e && e[0] == '0'); }();
+    q.xcd_n = (on && q.tilesN >= 8 && (int64_t)p.bytesw > (int64_t)p.bytes0 + (int64_t)p.bytes1) ? 1 : 0;
+  }
   const int grid = q.tilesM * q.tilesN;
   constexpr int NW = WM * WN, SLAB = 1024 * NW, ROWB = BK * 2;
   constexpr int A_BYTES = (BM * ROWB + SLAB - 1) / SLAB * SLAB, B_BYTES = (BN * ROWB + SLAB - 1) / SLAB * SLAB;
@@ -1951,6 +1966,7 @@ extern "C" int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream) {
   p.flags = d->flags;
   p.alpha = d->alpha;
   p.tilesM = p.tilesN = 0;
+  p.xcd_n = 0;
   hipStream_t s = (hipStream_t)stream;
   // tile field: low byte = tile id (0 = auto); bit 8 forces BK = 32, bit 9 selects the
   // alternative pipeline depth (tuning / testing)
