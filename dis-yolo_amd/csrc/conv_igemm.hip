@@ -41,6 +41,7 @@ struct ConvParams {
   int M, K, nk;
   unsigned bytes0, bytes1, bytesw;
   int tilesM, tilesN;
+  int pcls, Mc, tilesMc;     // stride-2 data gradient by output-parity classes (GEMM tiles): see conv_igemm_kernel
   int xcd_n;                 // GEMM tiles: an XCD's run of tiles walks the pixel tiles of a few channel tiles (weights > input)
   int flags;
   float alpha;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
   const int kg = KG == 1 ? 0 : wave_all / NW;     // K group of this wave
   const int wave = KG == 1 ? wave_all : wave_all % NW;
   const int wm = wave / WN, wn = wave % WN;
-  const int nkg = p.nk / KG;                      // K slices per group (the launcher guarantees divisibility)
+  int nkg = p.nk / KG;                            // K slices per group (the launcher guarantees divisibility)
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a
   // contiguous run of tiles, n-tile fastest, so the blocks that re-read one pixel panel
@@ -165,6 +166,35 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
     mt = tile / p.tilesN;
     nt = tile - mt * p.tilesN;
   }
+  // Stride-2 data gradient (in_div = 2: dx[y, x] takes tap (kh, kw) only where y + kh - pad and x + kw - pad are even):
+  // with pixels in their natural order every tile multiplies all 9 taps and 3/4 of the products are structural zeros.
+  // pcls: the pixel tiles are formed per output-parity class (y & 1, x & 1) instead -- 4 x tilesMc tiles over the Mc =
+  // B * Ho/2 * Wo/2 pixels of a class -- so that a tap is valid or void for a WHOLE tile, and the void ones (5, 6, 6 or 8
+  // of 9) are skipped: no DMA, no MFMA.  Pixel index of a class -> (b, yy, xx) -> (2 yy + py, 2 xx + px).
+  const bool pcl = KS == 3 && KG == 1 && p.pcls != 0;
+  int cls_py = 0, cls_px = 0;
+  if (pcl) {
+    const int cls = mt / p.tilesMc;
+    mt -= cls * p.tilesMc;
+    cls_py = cls >> 1;
+    cls_px = cls & 1;
+  }
+  auto tap_ok = [&](int kh_, int kw_) { return !pcl || ((((cls_py + kh_ - p.pad_t) | (cls_px + kw_ - p.pad_l)) & 1) == 0); };
+  const int Mlim = pcl ? p.Mc : p.M;
+  const int Hh = p.Ho >> 1, Wh = p.Wo >> 1;
+  // (class-local pixel index) -> pixel index of the output tensor
+  auto opix = [&](int m) {
+    if (!pcl) return m;
+    int b_, rem_, yy_, xx_;
+    divmod_small(m, Hh * Wh, b_, rem_);
+    divmod_small(rem_, Wh, yy_, xx_);
+    return (b_ * p.Ho + 2 * yy_ + cls_py) * p.Wo + 2 * xx_ + cls_px;
+  };
+  if (pcl) {
+    int nv = 0;
+    for (int t = 0; t < 9; ++t) nv += tap_ok(t / 3, t % 3) ? 1 : 0;
+    nkg = nv * (p.Cin / BK);
+  }
   const int m0 = mt * BM, n0 = nt * BN;
 
   // ---- per-lane gather state.  DMA j of this wave fills LDS bytes
@@ -183,10 +213,15 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
     const int chunk = (j * NW + wave) * 64 + lane;
     const int row = chunk / CPR, pc = chunk % CPR;
     const int m = ((p.flags & 0x1000) ? 0 : m0) + row;   // 0x1000: timing probe, every block gathers tile 0
-    a_ok[j] = (row < BM) && (m < p.M);
+    a_ok[j] = (row < BM) && (m < Mlim);
     const int mm = a_ok[j] ? m : 0;
     int b, rem, yo, xo;
-    if (p.M < (1 << 24)) {
+    if (pcl) {
+      divmod_small(mm, Hh * Wh, b, rem);
+      divmod_small(rem, Wh, yo, xo);
+      yo = 2 * yo + cls_py;
+      xo = 2 * xo + cls_px;
+    } else if (p.M < (1 << 24)) {
       divmod_small(mm, p.Ho * p.Wo, b, rem);
       divmod_small(rem, p.Wo, yo, xo);
     } else {
@@ -220,6 +255,16 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
 
   int kh = 0, kw = 0, ci0 = 0, k0 = 0;  // wave-uniform K cursor of the next tile to fetch
   bool newtap = true;
+  auto skip_void_taps = [&]() {         // (pcls) step over the taps this tile's parity class never sees
+    while (kh < 3 && !tap_ok(kh, kw)) {
+      k0 += p.Cin;
+      if (++kw == 3) {
+        kw = 0;
+        ++kh;
+      }
+    }
+  };
+  if (pcl) skip_void_taps();
   auto advance = [&]() {  // move the K cursor by one BK-wide slice
     k0 += BK;
     ci0 += BK;
@@ -230,6 +275,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
         kw = 0;
         ++kh;
       }
+      if (pcl) skip_void_taps();
     }
   };
   if (KG > 1)
@@ -513,8 +559,8 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
           v[r] = acc[i][j][r] * sc[r] + sh[r];
           if (p.flags & DISYOLO_CONV_LEAKY) v[r] = leaky(v[r], p.alpha);
         }
-        if (p.residual && m < p.M && n < p.Cout) {
-          const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.Cout + n);
+        if (p.residual && m < Mlim && n < p.Cout) {
+          const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)opix(m) * p.Cout + n);
           v[0] += __builtin_bit_cast(float, rr.x << 16);
           v[1] += __builtin_bit_cast(float, rr.x & 0xffff0000u);
           v[2] += __builtin_bit_cast(float, rr.y << 16);
@@ -537,8 +583,8 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
       const int idx = it * 64 + lane;
       const int row = idx / CPR8, ch = idx % CPR8;
       const int m = m0 + wm * WTM + row, n = n0 + wn * WTN + ch * 8;
-      if (idx < CH && m < p.M && n < p.Cout)
-        *reinterpret_cast<uint4*>(yo + (size_t)m * p.Cout + n) = *reinterpret_cast<const uint4*>(sw + row * ROWP + ch * 16);
+      if (idx < CH && m < Mlim && n < p.Cout)
+        *reinterpret_cast<uint4*>(yo + (size_t)opix(m) * p.Cout + n) = *reinterpret_cast<const uint4*>(sw + row * ROWP + ch * 16);
     }
     return;
   }
@@ -558,14 +604,14 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = m0 + wm * WTM + i * 16 + px;
-      if (m >= p.M) continue;
+      if (m >= Mlim) continue;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         v[r] = acc[i][j][r] * sc[r] + sh[r];
         if (p.flags & DISYOLO_CONV_LEAKY) v[r] = leaky(v[r], p.alpha);
       }
-      const size_t off = (size_t)m * p.Cout + n;
+      const size_t off = (size_t)opix(m) * p.Cout + n;
       if (vec_ok) {
         if (p.residual) {
           const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + off);
@@ -1711,6 +1757,16 @@ int launch_ks(const ConvParams& p, hipStream_t s) {
   q.tilesM = ceil_div(p.M, BM);
   q.tilesN = ceil_div(p.Cout, BN);
   q.nk = p.K / BK;
+  q.pcls = 0; q.Mc = 0; q.tilesMc = 0;
+  if (KS == 3 && KG == 1 && p.dshift == 1 && !(p.Ho & 1) && !(p.Wo & 1) && !(p.flags & DISYOLO_CONV_STATS)) {
+    static const bool on = [] { const char* e = getenv("DISYOLO_DGRAD_PCLS"); return !(e && e[0] == '0'); }();
+    if (on) {
+      q.pcls = 1;
+      q.Mc = p.B * (p.Ho >> 1) * (p.Wo >> 1);
+      q.tilesMc = ceil_div(q.Mc, BM);
+      q.tilesM = 4 * q.tilesMc;
+    }
+  }
   {
     static const bool on = [] { const char* e = getenv("DISYOLO_XCD_N"); return !(e && e[0] == '0'); }();
     q.xcd_n = (on && q.tilesN >= 8 && (int64_t)p.bytesw > (int64_t)p.bytes0 + (int64_t)p.bytes1) ? 1 : 0;
@@ -1967,6 +2023,7 @@ extern "C" int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream) {
   p.alpha = d->alpha;
   p.tilesM = p.tilesN = 0;
   p.xcd_n = 0;
+  p.pcls = 0; p.Mc = 0; p.tilesMc = 0;
   hipStream_t s = (hipStream_t)stream;
   // tile field: low byte = tile id (0 = auto); bit 8 forces BK = 32, bit 9 selects the
   // alternative pipeline depth (tuning / testing)

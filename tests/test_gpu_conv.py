@@ -510,6 +510,38 @@ def test_conv_dgrad_matches_autograd(dev, B, H, W, Cin, Cout, k, s):
     check(dx, want, 2.0 ** -7, 2e-3)
 
 
+# stride-2 data gradients by output-parity classes (even output sizes; the GEMM tiles): several tiles per class, ragged class
+# size, every tile shape, both BK, accumulation into an existing gradient
+DGRAD_S2 = [(2, 36, 36, 32, 64, 0, False), (2, 36, 36, 32, 64, 2, True), (1, 40, 24, 64, 128, 12, False), (3, 20, 28, 64, 128, 3, True),
+            (2, 48, 48, 32, 64, 4, False), (1, 72, 72, 32, 64, 0x206, True), (2, 22, 26, 128, 256, 0x10c, False), (2, 12, 16, 512, 1024, 3, False)]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,tile,accumulate", DGRAD_S2)
+def test_stride2_dgrad_by_parity_classes(dev, B, H, W, Cin, Cout, tile, accumulate):
+    """dx of a 3x3 stride-2 conv: a tap reaches an input pixel only where the parities match, so the GEMM tiles are formed
+    per output-parity class and skip the 5-8 void taps of their class.  Against autograd (f64), with and without a gradient
+    already in dx (residual = dx: the second consumer of a tensor), and bit for bit against the all-taps order
+    (DISYOLO_DGRAD_PCLS=0 is read once per process, so that comparison lives in tools/; here: values)."""
+    g = torch.Generator().manual_seed(Cin + Cout + H + tile)
+    x = torch.randn(B, H, W, Cin, generator=g, dtype=torch.float64, requires_grad=True)
+    w = bf16r(torch.randn(3, 3, Cin, Cout, generator=g) / (9 * Cin) ** 0.5)
+    y = O.conv2d_same(x, w, 2)
+    dy = bf16r(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    prev = bf16r(torch.randn(B, H, W, Cin, generator=g)) if accumulate else None
+    want = x.grad + (prev if accumulate else 0.0)
+    _, pt, _ = O.same_pads(H, 3, 2)
+    _, pl, _ = O.same_pads(W, 3, 2)
+    wdg = torch.empty(Cin, 9 * Cout, dtype=torch.bfloat16, device=dev)
+    L.pack_weights(w.float().to(dev), None, wdg, 3, Cin, Cout, Cout)
+    dx = prev.to(torch.bfloat16).to(dev) if accumulate else torch.full((B, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=dev)
+    d = L.make_conv_desc(dy.to(torch.bfloat16).to(dev), wdg, dx, 3, 1, in_div=2, pads=(2 - pt, 2 - pl), out_hw=(H, W),
+                         residual=dx if accumulate else None, tile=tile)
+    L.conv2d_fwd(d)
+    torch.cuda.synchronize()
+    check(dx, want, 2.0 ** -7, 2e-3)
+
+
 WGRAD = [(2, 18, 18, 64, 128, 3, 1), (2, 12, 12, 128, 64, 1, 1), (1, 20, 20, 32, 64, 3, 2), (2, 18, 18, 256, 24, 1, 1),
          (1, 24, 24, 64, 9, 1, 1), (3, 10, 10, 96, 32, 1, 1), (2, 36, 36, 32, 64, 3, 1),
          # the tap-fused 3x3 kernel: every ring size (W+1 = 73 / 145 / 289 / 421), both channel tiles, batches
