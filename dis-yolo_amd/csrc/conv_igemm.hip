@@ -723,7 +723,16 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int mt = tile / p.tilesN, nt = tile - mt * p.tilesN;
+  // (xcd_n: where the weights outweigh the input -- the 18^2 layers -- an XCD's run goes patch fastest instead: the
+  //  blocks that share a channel tile's weights sit on one L2 and every XCD reads 1/8 of the weights, not all of them)
+  int mt, nt;
+  if (p.xcd_n) {
+    nt = tile / p.tilesM;
+    mt = tile - nt * p.tilesM;
+  } else {
+    mt = tile / p.tilesN;
+    nt = tile - mt * p.tilesN;
+  }
   const int n0 = nt * BN;
   const int tpi = tilesY * tilesX;             // patches per image
   const int b = mt / tpi, pr = mt - b * tpi;
@@ -1722,6 +1731,10 @@ int launch_halo(const ConvParams& p, Patch pt, hipStream_t s) {
   const int tilesY = p.H / pt.ph, tilesX = p.W / pt.pw;
   q.tilesM = p.B * tilesY * tilesX;
   q.tilesN = ceil_div(p.Cout, BN);
+  {
+    static const bool on = [] { const char* e = getenv("DISYOLO_XCD_N"); return !(e && e[0] == '0'); }();
+    q.xcd_n = (on && q.tilesN >= 8 && (int64_t)p.bytesw > (int64_t)p.bytes0) ? 1 : 0;
+  }
   constexpr int SLAB = NW * 1024, BIM = (9 * BN * 4 + NW * 64 - 1) / (NW * 64);
   // two stages (compute slice c while slice c+1 lands); a one-slice layer (32 input channels) uses the first only.
   // The epilogue's scratch (stats rows + per-wave staging tiles) must fit as well.
