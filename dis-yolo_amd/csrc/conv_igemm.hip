@@ -704,6 +704,13 @@ struct BnBwdLane {
 
 template <int NW, int FW, int NI>
 __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH, int PW, int tilesY, int tilesX) {
+#ifdef HALO_PROBE
+  // tools/probe_halo.py: with flag 0x200000 the stats pointer receives, per wave, s_memtime at [0] kernel entry, [1] first
+  // DMAs issued, [2] main loop done, [3] end of the epilogue, and s_memrealtime at entry in [4]
+  long long hp_t[5];
+  hp_t[0] = (long long)__builtin_amdgcn_s_memtime();
+  hp_t[4] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
   constexpr int BN = NI * 16;
   constexpr int SLAB = NW * 1024;
   constexpr int AIM = 4;                                        // halo DMAs per wave (<= 64*NW pixels)
@@ -816,6 +823,9 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
 
   const int nch = p.Cin >> 5;
   issue(0, 0);
+#ifdef HALO_PROBE
+  hp_t[1] = (long long)__builtin_amdgcn_s_memtime();
+#endif
   // Fragment registers are double-buffered over the taps: the LDS reads of tap T+1 are issued before the MFMAs of tap
   // T, so a group of MFMAs never waits for the round trip of its own operands.  (Round 2 read, waited lgkmcnt(0) and
   // multiplied one M fragment at a time, inside a wave-uniform branch per fragment: every 4 MFMAs paid a full LDS
@@ -873,6 +883,21 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
   for (int c = 0; c + 1 < nch; ++c) slice_body(std::bool_constant<true>{}, c);
   slice_body(std::bool_constant<false>{}, nch - 1);
   __syncthreads();
+#ifdef HALO_PROBE
+  hp_t[2] = (long long)__builtin_amdgcn_s_memtime();
+  struct HaloProbeEnd {
+    const ConvParams& p; long long* t; int wave, lane, nw;
+    __device__ ~HaloProbeEnd() {
+      if (p.flags & 0x200000) {
+        t[3] = (long long)__builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+          long long* o = reinterpret_cast<long long*>(p.stats) + ((size_t)blockIdx.x * nw + wave) * 8;
+          for (int k = 0; k < 5; ++k) o[k] = t[k];
+        }
+      }
+    }
+  } hp_end{p, hp_t, wave, lane, NW};
+#endif
 
   // ---- epilogue.  acc[t][j][r]: patch pixel q_of[t] (lane & 15), channel n0 + j*16 + 4*(lane>>4) + r
   const int cq = lane >> 4;
