@@ -211,6 +211,33 @@ def test_config0_single_image_576_forward_matches_oracle(dev):
     assert (wb[0][:, 0] >= 0.05 - 1e-6).all() and (wb[0][:, 2] <= 0.95 + 1e-6).all()
 
 
+@pytest.mark.parametrize("size,batch", [(576, 2), (832, 1)])
+def test_fused_launches_equal_the_layer_by_layer_forward_at_full_size(dev, size, batch, monkeypatch):
+    """Size-independent property of the fused launches (conv1+2, residual blocks 1-3, mask head): at the BASELINE sizes the
+    inference forward with them equals the layer-by-layer forward -- the same products, f32 sums in another order, each
+    intermediate rounded to bf16 where the unfused path stores it: the head logits and score maps agree well inside the
+    tolerance either path has against the oracle, and the plan really replaces the eleven layers."""
+    def run(fused):
+        monkeypatch.setenv("DISYOLO_FUSE_B64", "1" if fused else "0")
+        net = YOLONet(training=False, device=dev, image_size=size, batch_size=batch, stage=1, seed=3)
+        net.fuse_first_two = net.fuse_blocks = fused
+        plan = net._fusion_plan(False, 1, 82)
+        b = synthetic_batch(batch, size, seed=77)
+        preds, det, mask_pos = net.forward(b["images"], b["clip_window"], [0.3], is_training=False)
+        torch.cuda.synchronize()
+        return sorted(plan), [t.float().cpu().clone() for t in preds] + [mask_pos.float().cpu().clone()]
+    plan_f, out_f = run(True)
+    plan_u, out_u = run(False)
+    assert plan_f == [1, 2, 3, 4, 6, 7, 8, 9, 80, 81, 82] and plan_u == []
+    for a, b_ in zip(out_f, out_u):
+        assert torch.isfinite(a).all()
+        scale = float(b_.abs().max())
+        # (conv1 on split bf16 operands differs from the exact-f32 kernel by 2^-16 per product: ~3 % of act1's bf16 roundings
+        #  flip, and 80 layers carry that to 0.7 % of the outputs' norm -- a third of what either path is from the oracle)
+        assert float((a - b_).abs().max()) <= 2.0 ** -4 * scale, (float((a - b_).abs().max()), scale)
+        assert float((a - b_).norm() / b_.norm()) < 1.5e-2
+
+
 def test_empty_and_saturated_detection_edge_cases(dev):
     """no candidate above the threshold -> zero rows, count 0, evaluation returns the scalar
     0.0 mask (yolo/yolo3_net_pos.py:933); more than 30 survivors -> exactly 30, best first."""
