@@ -42,6 +42,7 @@ struct ConvParams {
   unsigned bytes0, bytes1, bytesw;
   int tilesM, tilesN;
   int pcls, Mc, tilesMc;     // stride-2 data gradient by output-parity classes (GEMM tiles): see conv_igemm_kernel
+  int tapmask, d2s_c;        // stride-2 data gradient as a 2x2-tap conv over dy with a depth-to-space store (disyolo_dgrad_s2_quad)
   int xcd_n;                 // GEMM tiles: an XCD's run of tiles walks the pixel tiles of a few channel tiles (weights > input)
   int flags;
   float alpha;
@@ -179,7 +180,12 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
     cls_py = cls >> 1;
     cls_px = cls & 1;
   }
-  auto tap_ok = [&](int kh_, int kw_) { return !pcl || ((((cls_py + kh_ - p.pad_t) | (cls_px + kw_ - p.pad_l)) & 1) == 0); };
+  // tapmask (bit kh*3+kw): the taps that exist at all -- the 2x2-tap conv of the quad data gradient walks 4 of the 9
+  const bool tmk = KS == 3 && KG == 1 && p.tapmask != 0;
+  auto tap_ok = [&](int kh_, int kw_) {
+    if (tmk) return ((p.tapmask >> (kh_ * 3 + kw_)) & 1) != 0;
+    return !pcl || ((((cls_py + kh_ - p.pad_t) | (cls_px + kw_ - p.pad_l)) & 1) == 0);
+  };
   const int Mlim = pcl ? p.Mc : p.M;
   const int Hh = p.Ho >> 1, Wh = p.Wo >> 1;
   // (class-local pixel index) -> pixel index of the output tensor
@@ -190,11 +196,22 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
     divmod_small(rem_, Wh, yy_, xx_);
     return (b_ * p.Ho + 2 * yy_ + cls_py) * p.Wo + 2 * xx_ + cls_px;
   };
-  if (pcl) {
+  if (pcl || tmk) {
     int nv = 0;
     for (int t = 0; t < 9; ++t) nv += tap_ok(t / 3, t % 3) ? 1 : 0;
     nkg = nv * (p.Cin / BK);
   }
+  // element offset of (pixel m, channel n) in the output tensor.  d2s_c = C > 0: the N axis is [class (py, px)][C] and the
+  // store is a depth-to-space -- pixel (b, yy, xx) of the conv's grid, class (py, px) -> pixel (2 yy + py, 2 xx + px) of a
+  // tensor with C channels
+  auto oaddr = [&](int m, int n) -> size_t {
+    if (p.d2s_c == 0) return (size_t)opix(m) * p.Cout + n;
+    const int cls = n / p.d2s_c, c = n - cls * p.d2s_c;
+    int b_, rem_, yy_, xx_;
+    divmod_small(m, p.Ho * p.Wo, b_, rem_);
+    divmod_small(rem_, p.Wo, yy_, xx_);
+    return ((size_t)(b_ * 2 * p.Ho + 2 * yy_ + (cls >> 1)) * (2 * p.Wo) + 2 * xx_ + (cls & 1)) * p.d2s_c + c;
+  };
   const int m0 = mt * BM, n0 = nt * BN;
 
   // ---- per-lane gather state.  DMA j of this wave fills LDS bytes
@@ -264,7 +281,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
       }
     }
   };
-  if (pcl) skip_void_taps();
+  if (pcl || tmk) skip_void_taps();
   auto advance = [&]() {  // move the K cursor by one BK-wide slice
     k0 += BK;
     ci0 += BK;
@@ -275,7 +292,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
         kw = 0;
         ++kh;
       }
-      if (pcl) skip_void_taps();
+      if (pcl || tmk) skip_void_taps();
     }
   };
   if (KG > 1)
@@ -560,7 +577,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
           if (p.flags & DISYOLO_CONV_LEAKY) v[r] = leaky(v[r], p.alpha);
         }
         if (p.residual && m < Mlim && n < p.Cout) {
-          const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)opix(m) * p.Cout + n);
+          const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + oaddr(m, n));
           v[0] += __builtin_bit_cast(float, rr.x << 16);
           v[1] += __builtin_bit_cast(float, rr.x & 0xffff0000u);
           v[2] += __builtin_bit_cast(float, rr.y << 16);
@@ -584,7 +601,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
       const int row = idx / CPR8, ch = idx % CPR8;
       const int m = m0 + wm * WTM + row, n = n0 + wn * WTN + ch * 8;
       if (idx < CH && m < Mlim && n < p.Cout)
-        *reinterpret_cast<uint4*>(yo + (size_t)opix(m) * p.Cout + n) = *reinterpret_cast<const uint4*>(sw + row * ROWP + ch * 16);
+        *reinterpret_cast<uint4*>(yo + oaddr(m, n)) = *reinterpret_cast<const uint4*>(sw + row * ROWP + ch * 16);
     }
     return;
   }
@@ -611,7 +628,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
         v[r] = acc[i][j][r] * sc[r] + sh[r];
         if (p.flags & DISYOLO_CONV_LEAKY) v[r] = leaky(v[r], p.alpha);
       }
-      const size_t off = (size_t)opix(m) * p.Cout + n;
+      const size_t off = oaddr(m, n);
       if (vec_ok) {
         if (p.residual) {
           const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + off);
@@ -2021,6 +2038,79 @@ extern "C" int disyolo_conv2d_tile(const disyolo_conv_desc* d, int* bm, int* bn,
   return DISYOLO_E_ARG;
 }
 
+// ---- stride-2 3x3 data gradient as ONE 2x2-tap conv over dy with a depth-to-space store ("quad") ---------------------
+// dx[y, x, c] = sum over (kh, kw, ci) with y - kh and x - kw even of dy[(y - kh) / 2, (x - kw) / 2, ci] * w[kh, kw, c, ci]
+// (SAME padding of an even-sized input: pad_top = pad_left = 0).  All four output-parity classes of the quad
+// (2 yy + py, 2 xx + px) read dy rows yy - 1, yy and columns xx - 1, xx: a stride-1 conv over dy with the four taps
+// (a, b) in {0, 1}^2 of a padded 3x3 (a = 0: row yy - 1), N = [class][c], and per class only the taps of its parity
+// non-zero (9 of the 16 class x tap blocks).  Against the parity-class tiling of the generic kernel (exact FLOPs, but
+// 4 x M/BM tiles of 1-4 K slices each) this issues 1.75x the useful MFMAs in M/BM tiles of 4 full K slices: the shallow
+// layers (conv2: 663 k quads x 32 channels, conv5) are bound by the tiles' fixed cost, not by the matrix pipe.
+namespace {
+__global__ void pack_quad_kernel(const float* w, bf16* wq, int C, int Cdy) {
+  // wq [4 C][9 Cdy]: row (py*2 + px)*C + c, column (a*3 + b)*Cdy + ci
+  const int64_t n = (int64_t)4 * C * 9 * Cdy;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cdy);
+    const int tap = (int)((i / Cdy) % 9);
+    const int row = (int)(i / ((int64_t)9 * Cdy));
+    const int c = row % C, cls = row / C, py = cls >> 1, px = cls & 1;
+    const int a = tap / 3, b = tap % 3;
+    // class parity 0: kh = 0 at a = 1 (dy row yy), kh = 2 at a = 0 (row yy - 1); parity 1: kh = 1 at a = 1
+    const int kh = py == 0 ? (a == 1 ? 0 : (a == 0 ? 2 : -1)) : (a == 1 ? 1 : -1);
+    const int kw = px == 0 ? (b == 1 ? 0 : (b == 0 ? 2 : -1)) : (b == 1 ? 1 : -1);
+    float v = 0.f;
+    if (kh >= 0 && kw >= 0) v = w[((size_t)(kh * 3 + kw) * C + c) * Cdy + ci];      // HWIO [3][3][C][Cdy]
+    wq[i] = (bf16)v;
+  }
+}
+}  // namespace
+
+extern "C" int disyolo_pack_quad(const float* w_hwio, void* wq, int C, int Cdy, void* stream) {
+  DY_REQUIRE(w_hwio && wq && C > 0 && Cdy > 0, "pack_quad: bad args");
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_pack_quad(w_hwio, wq, C, Cdy, s); });
+  const int64_t n = (int64_t)4 * C * 9 * Cdy;
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(pack_quad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, (bf16*)wq, C, Cdy);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+extern "C" int disyolo_dgrad_s2_quad_ok(int B, int Hdy, int Wdy, int Cdy, int C) {
+  return (B > 0 && Hdy > 0 && Wdy > 0 && Cdy % 64 == 0 && C % 8 == 0 && (4 * C) % 128 == 0 && C <= 64 &&
+          (int64_t)B * Hdy * Wdy * 4 * C * 2 < (1LL << 31) && (int64_t)B * Hdy * Wdy * Cdy * 2 < (1LL << 31)) ? 1 : 0;
+}
+
+extern "C" int disyolo_dgrad_s2_quad(const void* dy, const void* wq, void* dx, const void* residual, int B, int Hdy, int Wdy,
+                                     int Cdy, int C, void* stream) {
+  DY_REQUIRE(dy && wq && dx, "dgrad_s2_quad: null pointer");
+  DY_REQUIRE(disyolo_dgrad_s2_quad_ok(B, Hdy, Wdy, Cdy, C) == 1, "dgrad_s2_quad: needs Cdy %% 64 == 0, C in {32, 64}");
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_dgrad_s2_quad(dy, wq, dx, residual, B, Hdy, Wdy, Cdy, C, s); });
+  ConvParams p;
+  p.x0 = (const bf16*)dy; p.x1 = nullptr; p.w = (const bf16*)wq;
+  p.scale = nullptr; p.shift = nullptr; p.residual = (const bf16*)residual; p.y = dx; p.stats = nullptr;
+  p.bn_x = nullptr; p.bn_scale = p.bn_shift = p.bn_mean = p.bn_rstd = nullptr; p.bn_part = nullptr; p.bn_alpha = 0.f;
+  p.B = B; p.H = Hdy; p.W = Wdy; p.C0 = Cdy; p.C1 = 0; p.Cin = Cdy;
+  p.Ho = Hdy; p.Wo = Wdy; p.Cout = 4 * C;
+  p.ks = 3; p.stride = 1; p.pad_t = 1; p.pad_l = 1; p.dmask = 0; p.dshift = 0;
+  p.M = B * Hdy * Wdy;
+  p.K = 9 * Cdy;
+  p.bytes0 = (unsigned)((size_t)B * Hdy * Wdy * Cdy * 2);
+  p.bytes1 = 0;
+  p.bytesw = (unsigned)((size_t)4 * C * 9 * Cdy * 2);
+  p.nk = 0;
+  p.flags = 0;
+  p.alpha = 0.f;
+  p.tilesM = p.tilesN = 0;
+  p.xcd_n = 0;
+  p.pcls = 0; p.Mc = 0; p.tilesMc = 0;
+  p.tapmask = 0x1b;           // taps (0,0) (0,1) (1,0) (1,1)
+  p.d2s_c = C;
+  // 192x128 tiles (8 waves of 48x64): 122 / 79 us on conv2 / conv5 at B = 8, cold caches, against 136-172 / 95-110 us for
+  // the 128x128, 64x128 and 256x128 tiles (tools/bench_quad.py)
+  return launch<192, 128, 4, 2, 64, 2>(p, (hipStream_t)stream);
+}
+
 extern "C" int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream) {
   int rc = validate(d);
   if (rc) return rc;
@@ -2062,6 +2152,7 @@ extern "C" int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream) {
   p.tilesM = p.tilesN = 0;
   p.xcd_n = 0;
   p.pcls = 0; p.Mc = 0; p.tilesMc = 0;
+  p.tapmask = 0; p.d2s_c = 0;
   hipStream_t s = (hipStream_t)stream;
   // tile field: low byte = tile id (0 = auto); bit 8 forces BK = 32, bit 9 selects the
   // alternative pipeline depth (tuning / testing)

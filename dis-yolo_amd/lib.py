@@ -58,6 +58,9 @@ _SIGS = {
     "disyolo_conv12_fused_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
     "disyolo_block32_fused_ok": (C.c_int, [C.c_int] * 6),
     "disyolo_block64_fused_ok": (C.c_int, [C.c_int] * 4),
+    "disyolo_pack_quad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "disyolo_dgrad_s2_quad_ok": (C.c_int, [C.c_int] * 5),
+    "disyolo_dgrad_s2_quad": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
     "disyolo_block64_fused_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "disyolo_block32_fused_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int] +
                                   [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
@@ -535,6 +538,33 @@ def block32_fused_fwd(x0, x1, wA, scaleA, shiftA, wB, scaleB, shiftB, y, post=0,
         flops = 2.0 * M * (32 * (C0 + C1) + 64 * 288 + (64 * 9 if post else 0))
         nbytes = M * C0 * 2 + (M // 4) * C1 * 2 + (M * 36 if post else M * 128)
         TIMER.run("block32_kernel<%d,%d>" % (C0 + C1, post), flops, fn, float(nbytes))
+        return
+    fn()
+
+
+def dgrad_s2_quad_ok(B: int, Hdy: int, Wdy: int, Cdy: int, C: int) -> bool:
+    return load().disyolo_dgrad_s2_quad_ok(B, Hdy, Wdy, Cdy, C) == 1
+
+
+def pack_quad(w_hwio, wq) -> None:
+    """f32 HWIO master [3,3,C,Cdy] of a stride-2 conv -> the bf16 operand [4C, 9*Cdy] of dgrad_s2_quad"""
+    _need(w_hwio, torch.float32, "w")
+    _need(wq, torch.bfloat16, "wq")
+    C_, Cdy = w_hwio.shape[2], w_hwio.shape[3]
+    _check(load().disyolo_pack_quad(_p(w_hwio), _p(wq), C_, Cdy, _stream()), "pack_quad")
+
+
+def dgrad_s2_quad(dy, wq, dx, accumulate: bool = False) -> None:
+    """data gradient of a 3x3 stride-2 conv (even input size, C <= 64): dx [B,2H,2W,C] (+)= quad conv of dy [B,H,W,Cdy]"""
+    _need(dy, torch.bfloat16, "dy")
+    _need(dx, torch.bfloat16, "dx")
+    B, H, W, Cdy = dy.shape
+    C_ = dx.shape[-1]
+    fn = lambda: _check(load().disyolo_dgrad_s2_quad(_p(dy), _p(wq), _p(dx), _p(dx) if accumulate else None, B, H, W, Cdy, C_,
+                                                      _stream()), "dgrad_s2_quad")
+    if TIMER is not None:
+        TIMER.run("conv_igemm_kernel<192,128,4,2,64,2,3,1>", 2.0 * B * H * W * 4 * C_ * 4 * Cdy, fn,
+                  float(B * H * W * (Cdy + 4 * C_) * 2))
         return
     fn()
 

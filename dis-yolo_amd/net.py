@@ -35,7 +35,7 @@ class Layer:
                  "Wo", "w", "bias", "gamma", "beta", "mm", "mv", "scale", "shift", "mean", "rstd", "wp", "wdg", "raw",
                  "act", "stats", "stats_rows", "desc", "grad", "grad_set", "need_grad", "dw", "dbias", "dgamma",
                  "dbeta", "dx", "pad_t", "pad_l", "dgrad_descs", "wgrad_desc", "cout_pad",
-                 "act8", "w8", "s_w", "s_out", "escale", "desc8", "dual16", "bn_sums", "bwd_local", "bwd_global", "bwd_part", "bwd_part_rows")
+                 "act8", "w8", "s_w", "s_out", "escale", "desc8", "dual16", "bn_sums", "bwd_local", "bwd_global", "bwd_part", "bwd_part_rows", "wq")
 
     def __init__(self, idx, cin, cout, k, stride, kind, src, src_up=None, shortcut=None):
         self.idx, self.cin, self.cout, self.k, self.stride, self.kind = idx, cin, cout, k, stride, kind
@@ -588,7 +588,15 @@ class YOLONet(object):
             pads = (l.k - 1 - l.pad_t, l.k - 1 - l.pad_l)
             if l.src_up is None:
                 tgt = self.by_idx[l.src]
-                l.dgrad_descs.append(("direct", tgt, dict(w=l.wdg, pads=pads, out_hw=(l.H, l.W))))
+                kw = dict(w=l.wdg, pads=pads, out_hw=(l.H, l.W))
+                # the shallow stride-2 layers (conv2, conv5): data gradient as one 2x2-tap conv over dy (lib.dgrad_s2_quad)
+                if (l.k == 3 and l.stride == 2 and l.H % 2 == 0 and l.W % 2 == 0 and l.pad_t == 0 and l.pad_l == 0
+                        and os.environ.get("DISYOLO_DGRAD_QUAD", "1") != "0"
+                        and L.dgrad_s2_quad_ok(self.B, l.Ho, l.Wo, l.cout, l.cin)):
+                    if getattr(l, "wq", None) is None:
+                        l.wq = torch.zeros(4 * l.cin, 9 * l.cout, dtype=BF16, device=self.device)
+                    kw["quad"] = l
+                l.dgrad_descs.append(("direct", tgt, kw))
             else:
                 skip, up = self.by_idx[l.src], self.by_idx[l.src_up]
                 if self._needs_grad_into[skip.idx]:
@@ -941,6 +949,11 @@ class YOLONet(object):
         epilogue also emits tgt's batch-norm backward sums (bn_act_bwd then skips its column reduction)"""
         out = desc_kw.get("tmp", tgt.grad)
         first = not tgt.grad_set
+        if "quad" in desc_kw and L.TUNER is None:
+            ql = desc_kw["quad"]
+            L.pack_quad(ql.w, ql.wq)       # (from the f32 master: the weights of THIS step, the update comes after the backward pass)
+            L.dgrad_s2_quad(dx, ql.wq, tgt.grad, accumulate=not first)
+            return
         res = None if (first or "tmp" in desc_kw) else tgt.grad
         d = L.make_conv_desc(dx, desc_kw["w"], out, k, 1, in_div=in_div, pads=desc_kw["pads"], out_hw=desc_kw["out_hw"],
                              residual=res)

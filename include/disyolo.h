@@ -162,6 +162,17 @@ int disyolo_block64_fused_fwd(const void* x, const void* wA, const float* scaleA
                               const float* scaleB, const float* shiftB, void* y, int B, int H, int W, int C0, float alpha,
                               void* stream);
 
+/* Data gradient of a 3x3 stride-2 SAME conv over an even-sized input (TF autodiff of tf.nn.conv2d wrt its input,
+ * train_yolo3_mask.py:55; conv2 / conv5 of the network, yolo/yolo3_net_pos.py:167,192) as one 2x2-tap conv over dy with a
+ * depth-to-space store: dx bf16 [B, 2 Hdy, 2 Wdy, C] (+= residual when given) from dy bf16 [B, Hdy, Wdy, Cdy] and wq =
+ * disyolo_pack_quad(w) (bf16 [4 C][9 Cdy], rebuilt from the f32 HWIO master [3][3][C][Cdy] whenever it changes).
+ * The generic path (disyolo_conv2d_fwd with in_div = 2) gives the same values; this one is for the shallow layers
+ * (C <= 64), where the generic tiles are bound by their fixed cost.  _ok: Cdy % 64 == 0, C in {32, 64}. */
+int disyolo_pack_quad(const float* w_hwio, void* wq, int C, int Cdy, void* stream);
+int disyolo_dgrad_s2_quad_ok(int B, int Hdy, int Wdy, int Cdy, int C);
+int disyolo_dgrad_s2_quad(const void* dy, const void* wq, void* dx, const void* residual, int B, int Hdy, int Wdy, int Cdy,
+                          int C, void* stream);
+
 /* weight gradient (TF autodiff of tf.nn.conv2d wrt filters; train_yolo3_mask.py:55):
  * dw[kh,kw,ci,co] (f32 HWIO, overwritten) = sum_m xcol[m,(kh,kw,ci)] * dy[m,co].
  * Uses d->x0/x1 (the layer input, same gather as forward) and `dy` bf16 [B*Ho*Wo, dy_ld]

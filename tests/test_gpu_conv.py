@@ -542,6 +542,36 @@ def test_stride2_dgrad_by_parity_classes(dev, B, H, W, Cin, Cout, tile, accumula
     check(dx, want, 2.0 ** -7, 2e-3)
 
 
+@pytest.mark.parametrize("B,H,W,C,Cdy,accumulate", [(2, 36, 36, 32, 64, False), (1, 40, 24, 64, 128, True), (3, 20, 28, 32, 64, True),
+                                                     (2, 64, 48, 32, 64, False), (1, 16, 16, 64, 128, False)])
+def test_stride2_dgrad_quad(dev, B, H, W, C, Cdy, accumulate):
+    """the shallow stride-2 layers' data gradient as one 2x2-tap conv over dy with a depth-to-space store (pack_quad +
+    dgrad_s2_quad) against autograd, and against the generic in_div = 2 path (same products, other summation order)"""
+    g = torch.Generator().manual_seed(C + Cdy + H)
+    x = torch.randn(B, H, W, C, generator=g, dtype=torch.float64, requires_grad=True)
+    w = bf16r(torch.randn(3, 3, C, Cdy, generator=g) / (9 * C) ** 0.5)
+    y = O.conv2d_same(x, w, 2)
+    dy = bf16r(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    prev = bf16r(torch.randn(B, H, W, C, generator=g)) if accumulate else None
+    want = x.grad + (prev if accumulate else 0.0)
+    assert L.dgrad_s2_quad_ok(B, H // 2, W // 2, Cdy, C)
+    wq = torch.full((4 * C, 9 * Cdy), float("nan"), dtype=torch.bfloat16, device=dev)
+    L.pack_quad(w.float().to(dev), wq)
+    dyd = dy.to(torch.bfloat16).to(dev)
+    dx = prev.to(torch.bfloat16).to(dev) if accumulate else torch.full((B, H, W, C), float("nan"), dtype=torch.bfloat16, device=dev)
+    L.dgrad_s2_quad(dyd, wq, dx, accumulate=accumulate)
+    torch.cuda.synchronize()
+    assert torch.isfinite(wq.float()).all()
+    check(dx, want, 2.0 ** -7, 2e-3)
+    wdg = torch.empty(C, 9 * Cdy, dtype=torch.bfloat16, device=dev)
+    L.pack_weights(w.float().to(dev), None, wdg, 3, C, Cdy, Cdy)
+    dx2 = prev.to(torch.bfloat16).to(dev) if accumulate else torch.empty(B, H, W, C, dtype=torch.bfloat16, device=dev)
+    L.conv2d_fwd(L.make_conv_desc(dyd, wdg, dx2, 3, 1, in_div=2, pads=(2, 2), out_hw=(H, W), residual=dx2 if accumulate else None))
+    torch.cuda.synchronize()
+    assert float((dx.float() - dx2.float()).abs().max()) <= 2.0 ** -6 * float(dx2.float().abs().max())
+
+
 WGRAD = [(2, 18, 18, 64, 128, 3, 1), (2, 12, 12, 128, 64, 1, 1), (1, 20, 20, 32, 64, 3, 2), (2, 18, 18, 256, 24, 1, 1),
          (1, 24, 24, 64, 9, 1, 1), (3, 10, 10, 96, 32, 1, 1), (2, 36, 36, 32, 64, 3, 1),
          # the tap-fused 3x3 kernel: every ring size (W+1 = 73 / 145 / 289 / 421), both channel tiles, batches
