@@ -211,7 +211,7 @@ def test_config0_single_image_576_forward_matches_oracle(dev):
     assert (wb[0][:, 0] >= 0.05 - 1e-6).all() and (wb[0][:, 2] <= 0.95 + 1e-6).all()
 
 
-@pytest.mark.parametrize("size,batch", [(576, 2), (832, 1)])
+@pytest.mark.parametrize("size,batch", [(576, 2), (832, 1), (96, 3), (160, 2)])
 def test_fused_launches_equal_the_layer_by_layer_forward_at_full_size(dev, size, batch, monkeypatch):
     """Size-independent property of the fused launches (conv1+2, residual blocks 1-3, mask head): at the BASELINE sizes the
     inference forward with them equals the layer-by-layer forward -- the same products, f32 sums in another order, each
@@ -228,7 +228,9 @@ def test_fused_launches_equal_the_layer_by_layer_forward_at_full_size(dev, size,
         return sorted(plan), [t.float().cpu().clone() for t in preds] + [mask_pos.float().cpu().clone()]
     plan_f, out_f = run(True)
     plan_u, out_u = run(False)
-    assert plan_f == [1, 2, 3, 4, 6, 7, 8, 9, 80, 81, 82] and plan_u == []
+    # (the 144^2-type blocks need a map width that is a multiple of 16: not at 96^2 / 160^2 inputs, which then run them
+    #  layer by layer -- the plan is per size)
+    assert plan_f == [1, 2, 3, 4] + ([6, 7, 8, 9] if (size // 4) % 16 == 0 else []) + [80, 81, 82] and plan_u == []
     for a, b_ in zip(out_f, out_u):
         assert torch.isfinite(a).all()
         scale = float(b_.abs().max())
