@@ -31,28 +31,43 @@ constexpr int NT = TH * TW;                         // 180 pixels
 constexpr int NW = 8;
 constexpr int NTF = (NT + 15) / 16;                 // 12 fragments: waves 0-3 take two, waves 4-7 one
 constexpr int CI = 128, CM = 64, CO = 128;
-constexpr int XP = CI * 2 + 16;                     // 272 bytes per input-tile pixel
+constexpr int XP = CI * 2;                          // 256 bytes per input-tile pixel: LDS-DMA writes 1 KB runs, so no padding -- the
+                                                    // 16-byte chunk c of pixel p sits at slot c ^ (p & 15) instead
 constexpr int MP = CM * 2 + 16;                     // 144 bytes per intermediate pixel
 constexpr int WP = CI * 2 + 16;                     // 272 bytes per row of the 1x1 weights
 constexpr int SROW = 80;                            // staging: 16 pixels x (64 B + pad)
 constexpr int CPP = CI / 8;                         // 16-byte chunks per pixel
-constexpr int NCH = NT * CPP;                       // 2880
-static_assert(NCH <= 6 * NW * 64, "three batches of two chunks per thread cover the tile");
-
-constexpr int X_BYTES = NTF * 16 * XP;              // 52224 (rows 180..191: scratch of the last fragment)
+constexpr int X_BYTES = NTF * 16 * XP;              // 49152 (rows 180..191: scratch of the last fragment)
 constexpr int M_BYTES = NTF * 16 * MP;              // 27648; the staging tiles (8 x 2 x 1280) live here after phase B
 constexpr int WA_BYTES = CM * WP;                   // 17408
 constexpr int BN_BYTES = (2 * CM + 2 * CO) * 4;     // 1536
-constexpr int DUMMY_BYTES = NW * 64 * 16;           // 8192
-constexpr unsigned X_OFF = 0, M_OFF = 2 * X_BYTES, WA_OFF = M_OFF + M_BYTES, BN_OFF = WA_OFF + WA_BYTES,
-                   DUMMY_OFF = BN_OFF + BN_BYTES;
-constexpr int LDS_BYTES = DUMMY_OFF + DUMMY_BYTES;
+constexpr unsigned X_OFF = 0, M_OFF = 2 * X_BYTES, WA_OFF = M_OFF + M_BYTES, BN_OFF = WA_OFF + WA_BYTES;
+constexpr int LDS_BYTES = BN_OFF + BN_BYTES;
+constexpr int NDMA = (NT * CPP + 63) / 64;          // 45 wave-wide 1 KB transfers per input tile
+constexpr unsigned OOB = 0x80000000u;
 static_assert(LDS_BYTES <= 160 * 1024, "one block per CU");
 // a base address ANDed with this is known to be non-negative, which is what hipcc needs to fold the compile-time part of
 // an LDS address into the instruction's 16-bit offset field (otherwise: one address register per access, hoisted, spilled)
 constexpr unsigned LDS_MASK = 0x3ffffu;
 static_assert(NW * 2 * 16 * SROW <= M_BYTES, "the staging tiles fit in the intermediate tile");
 static_assert(X_BYTES % 16 == 0 && M_BYTES % 16 == 0 && WA_BYTES % 16 == 0 && BN_BYTES % 16 == 0, "16-byte LDS regions");
+static_assert(NDMA <= 6 * NW, "six transfers per wave cover the tile");
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// one LDS-DMA: 64 lanes x 16 bytes, buffer descriptor + per-lane byte offset -> LDS (wave-uniform base in M0 + lane * 16);
+// lanes whose offset is past the descriptor's range get zeros (conv_igemm.hip has the long version of this comment)
+__device__ __forceinline__ void dma16(unsigned voff, i32x4 srd, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(srd), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ i32x4 make_srd(const void* base, unsigned bytes) {
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)base);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((size_t)base >> 32)) & 0xffff;
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+
 
 struct B64Params {
   const bf16* x;          // [B][H][W][128]
@@ -118,46 +133,26 @@ __global__ __launch_bounds__(NW * 64, 2) void block64_kernel(B64Params p) {
   // phase B: 16 lanes = 16 consecutive output columns; tile pixel (ph*4 + g + kh) * 18 + frow + kw
   const unsigned xb = M_OFF + (unsigned)((ph * 4 * TW + frow) * MP + cq * 16);
 
-  // input tile: chunk e = i * 512 + tid of the [180][16] tile (i < 6), fetched into registers and parked in THREE batches
-  // of two chunks per thread at different points of the previous patch (the 144 weight registers leave room for 8)
-  uint4 pre[1][2];
-  // is chunk e of the tile whose origin is (y0, x0) inside the image?  (wave-uniform shortcut for interior patches)
-  auto inside = [&](int e, int y0, int x0, bool border) {
-    if (!border) return e < NCH;
-    const int px = e >> 4;
-    const int ay = (px * 3641) >> 16, ax = px - ay * TW;         // px / 18 for px < 4096
-    return e < NCH && (unsigned)(y0 + ay) < (unsigned)p.H && (unsigned)(x0 + ax) < (unsigned)p.W;
-  };
-  auto fetch = [&](int b, int ty, int tx, int batch, auto set_tag) {
-    constexpr int SET = decltype(set_tag)::value;
+  // input tile by LDS-DMA: transfer i (wave i % 8 issues it) fills LDS bytes [i * 1024, +1024) of the buffer = slots
+  // (pixel, c') = ((i * 64 + lane) / 16, lane % 16); the lane fetches the LOGICAL chunk c' ^ (pixel & 15) of that pixel, or
+  // nothing (out of range: zeros) for the pixels outside the image and past the tile.  No registers, no park: the whole
+  // next tile is requested at the top of a patch and has the patch's three phases to land.
+  const i32x4 srdx = make_srd(p.x, (unsigned)((size_t)p.B * p.H * p.W * CI * 2));
+  auto fetch = [&](int b, int ty, int tx, unsigned xbase) {
     const int y0 = ty * PH - 1, x0 = tx * PW - 1;   // tile origin (may be -1)
-    const int64_t base = ((int64_t)(b * p.H + y0) * p.W + x0) * CI;
-    const bool border = ty == 0 || tx == 0 || ty == p.tilesY - 1 || tx == p.tilesX - 1;   // (uniform)
-    int t_ = tid;
-    asm volatile("" : "+v"(t_));                    // (the address arithmetic stays here: hoisted out of the patch loop it
-                                                    //  becomes thirty spilled registers)
+    int l_ = lane;
+    asm volatile("" : "+v"(l_));                    // (offsets computed here, per patch: hoisted they are registers)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int e = (batch * 2 + j) * (NW * 64) + t_;
-      const int px = e >> 4, ch = e & 15;
-      const int ay = (px * 3641) >> 16, ax = px - ay * TW;
-      // always a load, and nothing here looks at what it returns (park() zeroes what lies outside the image): the two
-      // loads stay in flight until they are parked
-      pre[SET][j] = *reinterpret_cast<const uint4*>(inside(e, y0, x0, border) ? p.x + base + ((ay * p.W + ax) * CI + ch * 8) : p.x);
-    }
-  };
-  auto park = [&](unsigned xbase, int ty, int tx, int batch, auto set_tag) {
-    constexpr int SET = decltype(set_tag)::value;
-    const int y0 = ty * PH - 1, x0 = tx * PW - 1;
-    const bool border = ty == 0 || tx == 0 || ty == p.tilesY - 1 || tx == p.tilesX - 1;
-    int t_ = tid;
-    asm volatile("" : "+v"(t_));
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int e = (batch * 2 + j) * (NW * 64) + t_;
-      const int px = e >> 4, ch = e & 15;
-      const unsigned a = e < NCH ? xbase + (unsigned)(px * XP + ch * 16) : DUMMY_OFF + (unsigned)t_ * 16;
-      *reinterpret_cast<uint4*>(smem + a) = inside(e, y0, x0, border) ? pre[SET][j] : uint4{0u, 0u, 0u, 0u};
+    for (int j = 0; j < 6; ++j) {
+      const int i = wave + NW * j;                  // (uniform)
+      if (i < NDMA) {
+        const int px = i * 4 + (l_ >> 4), cp = l_ & 15;
+        const int ay = (px * 3641) >> 16, ax = px - ay * TW;     // px / 18
+        const int y = y0 + ay, x = x0 + ax;
+        const bool ok = px < NT && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const unsigned off = ok ? (unsigned)((((b * p.H + y) * p.W + x) * CI + ((cp ^ (px & 15)) << 3)) * 2) : OOB;
+        dma16(off, srdx, xbase + (unsigned)i * 1024u);
+      }
     }
   };
 
@@ -172,7 +167,8 @@ __global__ __launch_bounds__(NW * 64, 2) void block64_kernel(B64Params p) {
       asm volatile("" : "+v"(q));                   // (addresses from q are computed here, per patch: see fetch())
       bf16x8 xf[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(smem + ((xbase + (unsigned)(q * XP + cq * 16)) & LDS_MASK) + ks * 64);
+      for (int ks = 0; ks < 4; ++ks)
+        xf[ks] = *reinterpret_cast<const bf16x8*>(smem + ((xbase + (unsigned)(q * XP + (((ks * 4 + cq) ^ (q & 15)) << 4))) & LDS_MASK));
       bool outside = false;
       if (EDGE) {
         const int ay = (q * 3641) >> 16, ax = q - ay * TW;
@@ -213,11 +209,8 @@ __global__ __launch_bounds__(NW * 64, 2) void block64_kernel(B64Params p) {
     ty = pr / p.tilesX;
     tx = pr - ty * p.tilesX;
   }
-  using S0 = std::integral_constant<int, 0>;
-  for (int batch = 0; batch < 3; ++batch) {
-    fetch(b, ty, tx, batch, S0{});
-    park(X_OFF, ty, tx, batch, S0{});
-  }
+  fetch(b, ty, tx, X_OFF);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                  // weights, tables, the first input tile
   unsigned cur = 0;
 #ifdef B64_PROBE
@@ -231,7 +224,7 @@ __global__ __launch_bounds__(NW * 64, 2) void block64_kernel(B64Params p) {
     if (ntx >= p.tilesX) { ntx -= p.tilesX; ++nty; }
     if (nty >= p.tilesY) { nty -= p.tilesY; ++nb; }
     const bool more = t + (int)gridDim.x < p.tiles;
-    if (more) fetch(nb, nty, ntx, 0, S0{});         // in flight under phase A
+    if (more) fetch(nb, nty, ntx, xnxt);            // the whole next tile: in flight under this patch (nobody reads that buffer)
     B64_STAMP(0);
     const unsigned edge_mask = (ty == 0 ? 1u : 0u) | (ty == p.tilesY - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) |
                                (tx == p.tilesX - 1 ? 8u : 0u);
@@ -240,10 +233,6 @@ __global__ __launch_bounds__(NW * 64, 2) void block64_kernel(B64Params p) {
     B64_STAMP(1);
     __syncthreads();                                // the intermediate tile is complete
     B64_STAMP(2);
-    if (more) {                                     // (the other input buffer: nobody reads it in this patch)
-      park(xnxt, nty, ntx, 0, S0{});
-      fetch(nb, nty, ntx, 1, S0{});                 // in flight under phase B
-    }
     B64_STAMP(3);
     // ---- phase B: 4 patch rows x 16 columns x 32 channels per wave
     f32x4 acc[4][2];
@@ -274,10 +263,6 @@ __global__ __launch_bounds__(NW * 64, 2) void block64_kernel(B64Params p) {
       }
     }
     B64_STAMP(4);
-    if (more) {
-      park(xnxt, nty, ntx, 1, S0{});
-      fetch(nb, nty, ntx, 2, S0{});                 // in flight under the epilogue
-    }
     __syncthreads();                                // everyone is done with the intermediate tile: its space is the staging now
     B64_STAMP(5);
     f32x2 s2[2][2], h2[2][2];
@@ -293,10 +278,11 @@ __global__ __launch_bounds__(NW * 64, 2) void block64_kernel(B64Params p) {
     for (int g = 0; g < 4; ++g) {
       char* const sw = sw0 + (g & 1) * (16 * SROW);
       // the residual: input-tile pixel (ph*4 + g + 1, frow + 1), channels cqt*32 + nf*16 + 4 cq .. +3
-      const char* rsrc = smem + xcur + ((ph * 4 + g + 1) * TW + frow + 1) * XP + (cqt * 32 + cq * 4) * 2;
+      const int rp = (ph * 4 + g + 1) * TW + frow + 1;          // tile pixel of the residual
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf) {
-        const uint2 rr = *reinterpret_cast<const uint2*>(rsrc + nf * 32);
+        // channels cqt*32 + nf*16 + 4 cq .. +3 = 8 bytes at (cq & 1) * 8 of chunk cqt*4 + nf*2 + (cq >> 1)
+        const uint2 rr = *reinterpret_cast<const uint2*>(smem + xcur + rp * XP + (((cqt * 4 + nf * 2 + (cq >> 1)) ^ (rp & 15)) << 4) + (cq & 1) * 8);
         f32x2 v0 = f32x2{acc[g][nf][0], acc[g][nf][1]} * s2[nf][0] + h2[nf][0];
         f32x2 v1 = f32x2{acc[g][nf][2], acc[g][nf][3]} * s2[nf][1] + h2[nf][1];
         const f32x2 t0 = v0 * alpha2, t1 = v1 * alpha2;
@@ -316,10 +302,10 @@ __global__ __launch_bounds__(NW * 64, 2) void block64_kernel(B64Params p) {
       *reinterpret_cast<uint4*>(p.y + m * CO + cqt * 32 + ch * 8) = *reinterpret_cast<const uint4*>(sw + px * SROW + ch * 16);
     }
     B64_STAMP(6);
-    if (more) park(xnxt, nty, ntx, 2, S0{});
     b = nb; ty = nty; tx = ntx;
     cur ^= 1u;
-    __syncthreads();                                // staging reads done; the parked input is visible
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next input tile has landed (and its stores left)
+    __syncthreads();                                // staging reads done; everyone's share of the next input tile is in LDS
     B64_STAMP(7);
   }
 #ifdef B64_PROBE
@@ -335,7 +321,7 @@ extern long long* g_b64_probe;
 #endif
 
 extern "C" int disyolo_block64_fused_ok(int B, int H, int W, int C0) {
-  return (C0 == CI && B > 0 && H > 0 && W > 0 && H % PH == 0 && W % PW == 0 && (int64_t)B * H * W * CI < (1LL << 31)) ? 1 : 0;
+  return (C0 == CI && B > 0 && H > 0 && W > 0 && H % PH == 0 && W % PW == 0 && (int64_t)B * H * W * CI * 2 < (1LL << 31)) ? 1 : 0;   // (32-bit DMA offsets, bit 31 = out of range)
 }
 
 extern "C" int disyolo_block64_fused_fwd(const void* x, const void* wA, const float* scaleA, const float* shiftA, const void* wB,
