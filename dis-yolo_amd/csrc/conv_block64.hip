@@ -55,7 +55,9 @@ static_assert(NDMA <= 6 * NW, "six transfers per wave cover the tile");
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 // one LDS-DMA: 64 lanes x 16 bytes, buffer descriptor + per-lane byte offset -> LDS (wave-uniform base in M0 + lane * 16);
-// lanes whose offset is past the descriptor's range get zeros (conv_igemm.hip has the long version of this comment)
+// lanes whose offset is past the descriptor's range get zeros (conv_igemm.hip has the long version of this comment).  The asm
+// writes M0 behind the compiler's back (m0 is not allowed on a clobber list): nothing else in this kernel uses it -- no
+// dynamic register indexing, and gfx9+ DS instructions do not read it; the 12 s_mov_b32 m0 of the build are all ours
 __device__ __forceinline__ void dma16(unsigned voff, i32x4 srd, unsigned lds_base) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(srd), "s"(lds_base) : "memory");
 }
