@@ -8,9 +8,10 @@
 // 147 KB) only fit in the registers of EIGHT waves (one persistent 8-wave block per CU, 144 VGPRs of weights per wave:
 // 32 output channels x 9 taps x 64 k), and the input tile is double-buffered in LDS instead of being held in registers over
 // both phases.  Per 8 x 16-pixel output patch:
-//   fetch    the 10 x 18 x 128 input tile of the NEXT patch into registers (6 x 16 bytes per thread), parked into the other
-//            input buffer after phase A;
-//   phase A  the 1x1 conv on the 180 tile pixels (12 fragments over 8 waves), K = 128 from the input tile, its weights
+//   fetch    the 10 x 18 x 128 input tile of the NEXT patch by LDS-DMA into the other input buffer, requested at the top of
+//            the patch (45 wave-wide 1 KB transfers, pixels outside the image out of the descriptor's range = zeros); 256-byte
+//            pixel rows, 16-byte chunk c of pixel p at slot c ^ (p & 15): no padding (DMA writes linear runs), no conflicts;
+//   phase A  the 1x1 conv on the 180 tile pixels (24 units of 16 pixels x 32 channels over 8 waves), K = 128, its weights
 //            (64 x 128) read from LDS as A fragments; folded BN + leaky, zero outside the image (the 3x3's SAME padding),
 //            bf16 tile [180][64] with 144-byte rows;
 //   phase B  the 3x3 conv from that tile: a wave owns 32 of the 128 channels and 4 of the 8 patch rows; per tap and
