@@ -117,6 +117,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 // where one wave per SIMD cannot overlap its DMA issue with its MFMAs.
 template <int BM, int BN, int WM, int WN, int BK, int ST, int KS, int KG = 1>
 __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1) void conv_igemm_kernel(ConvParams p) {
+#ifdef HALO_PROBE
+  // tools/probe_halo.py (probe build only): with flag 0x200000 the stats pointer receives, per wave, s_memtime at [0] entry,
+  // [1] pipeline primed, [2] main loop done, [3] end of the epilogue, s_memrealtime at entry in [4]
+  long long gp_t[5];
+  gp_t[0] = (long long)__builtin_amdgcn_s_memtime();
+  gp_t[4] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
   constexpr int NW = WM * WN;         // waves per K group
   constexpr int T = NW * 64;          // threads per K group
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -371,6 +378,9 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
 #pragma unroll
   for (int s = 0; s < PRE; ++s)
     if (s < nkg) issue_tile(s);
+#ifdef HALO_PROBE
+  gp_t[1] = (long long)__builtin_amdgcn_s_memtime();
+#endif
 
   const int frow = lane & 15, fchunk = lane >> 4;
 #ifdef DY_PROBE
@@ -495,6 +505,21 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
   }
 #ifdef DY_PROBE
   if ((p.flags & 0x80000) && acc[0][0][0] != 123.456f) return;   // timing probe: no epilogue
+#endif
+#ifdef HALO_PROBE
+  gp_t[2] = (long long)__builtin_amdgcn_s_memtime();
+  struct GemmProbeEnd {
+    const ConvParams& p; long long* t; int wave, lane, nw;
+    __device__ ~GemmProbeEnd() {
+      if (p.flags & 0x200000) {
+        t[3] = (long long)__builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+          long long* o = reinterpret_cast<long long*>(p.stats) + ((size_t)blockIdx.x * nw + wave) * 8;
+          for (int k = 0; k < 5; ++k) o[k] = t[k];
+        }
+      }
+    }
+  } gp_end{p, gp_t, wave_all, lane, NW * KG};
 #endif
   const bool ep = (KG == 1) || (kg == 0);   // only group 0 holds the full sums
   float* scsh = reinterpret_cast<float*>(smem + WM * BN * 8);   // [2][BN] behind the stats scratch

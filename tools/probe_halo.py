@@ -11,7 +11,10 @@ from disyolo_amd import lib as L
 
 dev = torch.device("cuda:0")
 bf = torch.bfloat16
-for (B, H, Cin, Cout, tile, nw) in ((8, 36, 256, 512, 16, 8), (8, 18, 512, 1024, 18, 8), (8, 72, 128, 256, 16, 8), (8, 18, 512, 1024, 16, 8)):
+CASES = ((8, 36, 256, 512, 16, 8), (8, 18, 512, 1024, 18, 8), (8, 72, 128, 256, 16, 8), (8, 18, 512, 1024, 16, 8),
+         # the 192x128 GEMM tile (8 waves of 48x64, two blocks per CU): training and inference batch
+         (8, 72, 128, 256, 12, 8), (32, 72, 128, 256, 12, 8), (32, 36, 256, 512, 12, 8), (32, 18, 512, 1024, 12, 8))
+for (B, H, Cin, Cout, tile, nw) in CASES:
     x = torch.randn(B, H, H, Cin, device=dev).to(bf)
     w = (torch.randn(Cout, 9 * Cin, device=dev) * 0.02).to(bf)
     y = torch.empty(B, H, H, Cout, dtype=bf, device=dev)
@@ -37,6 +40,7 @@ for (B, H, Cin, Cout, tile, nw) in ((8, 36, 256, 512, 16, 8), (8, 18, 512, 1024,
     print("   per wave, ticks at 2.4 GHz: setup %.0f | main loop %.0f | epilogue %.0f | total %.0f (= %.2f us)"
           % (np.median(t1 - t0), np.median(t2 - t1), np.median(t3 - t2), np.median(t3 - t0), np.median(t3 - t0) / 2400))
     print("   last block ends %.2f us after the first entry (realtime of entry + its own duration)" % ((ent + (t3 - t0) / 24).max() / 100))
+    order = np.sort(ent.min(1))
+    print("   block entries (us after the first), deciles: " + " ".join("%.1f" % (order[int(q * (len(order) - 1))] / 100) for q in np.linspace(0, 1, 11)))
     K = 9 * Cin
-    mf = (bm // 16 + 0) * 0
-    print("   MFMA-bound main loop: %.0f ticks per SIMD (%d px x %d ch x K %d per block)" % (2.0 * bm * bn * K / (4 * 16384) * 16.3 / 2, bm, bn, K))
+    print("   MFMA time of the block's main loop at the pipe's rate: %.0f ticks per SIMD (%d px x %d ch x K %d)" % (bm * bn * K / (16 * 16 * 32) / 4 * 16.3, bm, bn, K))
