@@ -1,9 +1,9 @@
 // The two HBM-bound [1x1 -> 32 channels] -> [3x3 32 -> 64] chains of the 288^2 maps in ONE launch each, for the steps in
 // which their batch norms run in inference mode (locked backbone of training stage 1 / every inference call):
 //
-//   residual block 1   act3 = leaky(bn3(conv1x1(act2)))           64 -> 32     yolo/yolo3_net_pos.py:172-189
+//   residual block 1   act3 = leaky(bn3(conv1x1(act2)))           64 -> 32     yolo/yolo3_net_pos.py:169-176
 //     (post 0)         act4 = leaky(bn4(conv3x3(act3))) + act2    32 -> 64
-//   mask head          act80 = leaky(bn(conv1x1([act4, up2(act79)])))   96 -> 32   yolo/yolo3_net_pos.py:455-476
+//   mask head          act80 = leaky(bn(conv1x1([act4, up2(act79)])))   96 -> 32   yolo/yolo3_net_pos.py:404-412
 //     (post 1)         act81 = leaky(bn(conv3x3(act80)))                32 -> 64
 //                      out   = conv1x1(act81) + bias                    64 -> 9 (k_map^2 position-sensitive score maps), f32
 //
@@ -395,7 +395,8 @@ int launch_block32(BParams& p, hipStream_t s) {
 
 extern "C" int disyolo_block32_fused_ok(int B, int H, int W, int C0, int C1, int post) {
   const bool shape = (C0 == 64 && C1 == 0 && post == 0) || (C0 == 64 && C1 == 32 && post == 1);
-  return (shape && B > 0 && H > 0 && W > 0 && H % PH == 0 && W % PW == 0 && (int64_t)B * H * W * 64 < (1LL << 31)) ? 1 : 0;
+  return (shape && B > 0 && H > 0 && W > 0 && H % PH == 0 && W % PW == 0 &&
+          (int64_t)B * H * W * 128 < (1LL << 31)) ? 1 : 0;   // bytes of the largest tensor (64 bf16 channels in / out; the f32 score maps are 36 B / pixel)
 }
 
 extern "C" int disyolo_block32_fused_fwd(const void* x0, const void* x1, int C0, int C1, const void* wA, const float* scaleA,

@@ -1,5 +1,5 @@
 // The residual blocks of the 144^2 maps ([1x1 128 -> 64] -> [3x3 64 -> 128] + block input; conv6+7 and conv8+9,
-// yolo/yolo3_net_pos.py:194-211) in ONE launch each, for the steps in which their batch norms run in inference mode (the
+// yolo/yolo3_net_pos.py:184-201) in ONE launch each, for the steps in which their batch norms run in inference mode (the
 // locked backbone of training stage 1, every inference call).  Unfused, a block moves 0.68 GB at B = 32 (input read twice,
 // the 64-channel intermediate written and read) for 0.34 GB of input + output; the 1x1 runs at the HBM bound, the 3x3 at
 // 135 us against 39 us of MFMA work.

@@ -2,7 +2,7 @@
 // of training stage 1; every inference call):
 //
 //   act1 = leaky(bn1(conv3x3_s1(image)))          yolo/yolo3_net_pos.py:159-161   (3 -> 32, 576^2 -> 576^2)
-//   act2 = leaky(bn2(conv3x3_s2(act1)))           yolo/yolo3_net_pos.py:167-169   (32 -> 64, 576^2 -> 288^2)
+//   act2 = leaky(bn2(conv3x3_s2(act1)))           yolo/yolo3_net_pos.py:165-167   (32 -> 64, 576^2 -> 288^2)
 //
 // act1 ("skip1", :163) has ONE consumer in the active m = 1/2 mask subnet configuration: conv2.  Stored, it is the
 // largest tensor of the network (B x 576 x 576 x 32 bf16 = 170 MB at B = 8) -- written once, read once, 0.34 GB of HBM
@@ -362,7 +362,8 @@ extern long long* g_f2_probe;
 
 extern "C" int disyolo_conv12_fused_ok(int B, int H, int W) {
   return (B > 0 && H > 0 && W > 0 && (H / 2) % PH2 == 0 && (W / 2) % PW2 == 0 && H % 2 == 0 && W % 2 == 0 &&
-          (int64_t)B * H * W * 3 < (1LL << 31)) ? 1 : 0;
+          // 32-bit byte offsets: the f32 image (12 B / pixel) and the bf16 output (64 channels at half resolution)
+          (int64_t)B * H * W * 12 < (1LL << 31) && (int64_t)B * (H / 2) * (W / 2) * 128 < (1LL << 31)) ? 1 : 0;
 }
 
 extern "C" int disyolo_conv12_fused_fwd(const float* images, const float* w1_hwio, const float* scale1, const float* shift1,

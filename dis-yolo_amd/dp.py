@@ -20,6 +20,8 @@ from typing import List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
+from .lib import DisyoloError
+
 
 def plan_buckets(layer_spans: List[Tuple[int, int, int]], bucket_elems: int) -> List[Tuple[int, int, int]]:
     """layer_spans: (layer_idx, offset, count) for the trainable layers' weight(+bias) slices,
@@ -173,7 +175,8 @@ class GradientAllReduce:
         out = []
         for i in range(n):
             out.append(round(sum(e[i].elapsed_time(e[i + 1]) for e in self.trace) / len(self.trace) * 1e3, 1))
-        sizes = [c * 4 / 1e6 for _, _, c in self.buckets] + [self.tail[1] * 4 / 1e6]
+        esz = 2 if self.wire == "bf16" else 4                  # bytes per element on the links
+        sizes = [c * esz / 1e6 for _, _, c in self.buckets] + [self.tail[1] * esz / 1e6]
         return {"exposed_wait_us": out, "bucket_mb": [round(x, 2) for x in sizes[:n]], "steps": len(self.trace),
                 "wire": self.wire, "algo": self.algo}
 
@@ -193,6 +196,9 @@ def enable_data_parallel(net, process_group=None, bucket_mb: float = 12.0, wire:
     rank starts from rank 0's variables (the reference has one process, hence one initialisation).
     ``sync_bn``: batch-norm statistics (forward moments and the two backward sums) over all ranks' batches,
     so that N ranks x b images train like one process with N*b images."""
+    if getattr(net, "pair", False):
+        # the pair step alternates two single-GPU lists and its eager form has no exchange point
+        raise DisyoloError("backbone_pair is a single-GPU option: build the net without it for data parallelism")
     wire = wire or os.environ.get("DISYOLO_DP_WIRE", "f32")
     algo = algo or os.environ.get("DISYOLO_DP_ALGO", "allreduce")
     net.dp = GradientAllReduce(net, process_group, bucket_mb, wire, algo)

@@ -200,6 +200,11 @@ def _need(t: torch.Tensor, dtype, name: str) -> None:
         raise DisyoloError("%s must be a contiguous CUDA tensor of %s (got %s on %s)" % (name, dtype, t.dtype, t.device))
 
 
+def _need_shape(t: torch.Tensor, shape, name: str) -> None:
+    if tuple(t.shape) != tuple(shape):
+        raise DisyoloError("%s must have shape %s (got %s)" % (name, tuple(shape), tuple(t.shape)))
+
+
 class Workspace:
     """Grow-only device scratch buffer handed to the kernels that need one.  Once a command
     list has captured its address it is frozen: a later request that does not fit raises
@@ -509,6 +514,7 @@ def conv12_fused_fwd(images, w1_hwio, scale1, shift1, w2_packed, scale2, shift2,
     _need(images, torch.float32, "images")
     _need(y, torch.bfloat16, "y")
     B, H, W, _ = images.shape
+    _need_shape(y, (B, H // 2, W // 2, 64), "conv12_fused_fwd: y")
     fn = lambda: _check(load().disyolo_conv12_fused_fwd(_p(images), _p(w1_hwio), _p(scale1), _p(shift1), _p(w2_packed), _p(scale2),
                                                         _p(shift2), _p(y), B, H, W, alpha, _stream()), "conv12_fused_fwd")
     if TIMER is not None:
@@ -530,6 +536,11 @@ def block32_fused_fwd(x0, x1, wA, scaleA, shiftA, wB, scaleB, shiftB, y, post=0,
     _need(y, torch.bfloat16 if post == 0 else torch.float32, "y")
     B, H, W, C0 = x0.shape
     C1 = 0 if x1 is None else x1.shape[-1]
+    # the C launcher takes B, H, W from x0 and cannot see the other buffers' sizes
+    if x1 is not None:
+        _need(x1, torch.bfloat16, "x1")
+        _need_shape(x1, (B, H // 2, W // 2, C1), "block32_fused_fwd: x1")
+    _need_shape(y, (B, H, W, 9 if post else 64), "block32_fused_fwd: y")
     fn = lambda: _check(load().disyolo_block32_fused_fwd(_p(x0), _p(x1), C0, C1, _p(wA), _p(scaleA), _p(shiftA), _p(wB), _p(scaleB),
                                                          _p(shiftB), post, _p(wC), _p(biasC), _p(y), B, H, W, alpha, _stream()),
                         "block32_fused_fwd")
@@ -578,6 +589,7 @@ def block64_fused_fwd(x, wA, scaleA, shiftA, wB, scaleB, shiftB, y, alpha=0.1) -
     _need(x, torch.bfloat16, "x")
     _need(y, torch.bfloat16, "y")
     B, H, W, C0 = x.shape
+    _need_shape(y, (B, H, W, C0), "block64_fused_fwd: y")
     fn = lambda: _check(load().disyolo_block64_fused_fwd(_p(x), _p(wA), _p(scaleA), _p(shiftA), _p(wB), _p(scaleB), _p(shiftB), _p(y),
                                                          B, H, W, C0, alpha, _stream()), "block64_fused_fwd")
     if TIMER is not None:
@@ -600,7 +612,9 @@ WGRAD_IM2COL, WGRAD_PARTIAL_ONLY, WGRAD_REDUCE_ONLY = 1, 2, 4
 
 def wgrad_stages(n: int) -> int:
     """opts bits for the im2col weight-gradient kernel's pipeline depth (2..4 stages)"""
-    return (n - 1) << 4
+    if not 2 <= int(n) <= 4:
+        raise DisyoloError("wgrad_stages: 2..4 pipeline stages (got %r)" % (n,))
+    return (int(n) - 1) << 4
 
 
 def conv2d_wgrad_workspace(d: ConvDesc, opts: int = 0) -> int:

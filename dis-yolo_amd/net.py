@@ -653,15 +653,15 @@ class YOLONet(object):
 
     def _forward_block34(self) -> None:
         l2, l3, l4 = self.by_idx[2], self.by_idx[3], self.by_idx[4]
-        L.block32_fused_fwd(l2.act, None, l3.wp, l3.scale, l3.shift, l4.wp, l4.scale, l4.shift, l4.act, post=0, alpha=cfg.ALPHA)
+        L.block32_fused_fwd(self._input_of(l3, 2), None, l3.wp, l3.scale, l3.shift, l4.wp, l4.scale, l4.shift, l4.act, post=0, alpha=cfg.ALPHA)
 
     def _forward_block64(self, i3: int) -> None:
         la, lb = self.by_idx[i3 - 1], self.by_idx[i3]
-        L.block64_fused_fwd(self.by_idx[la.src].act, la.wp, la.scale, la.shift, lb.wp, lb.scale, lb.shift, lb.act, alpha=cfg.ALPHA)
+        L.block64_fused_fwd(self._input_of(la, la.src), la.wp, la.scale, la.shift, lb.wp, lb.scale, lb.shift, lb.act, alpha=cfg.ALPHA)
 
     def _forward_mask_head(self) -> None:
         l80, l81, l82 = self.by_idx[80], self.by_idx[81], self.by_idx[82]
-        L.block32_fused_fwd(self.by_idx[l80.src].act, self.by_idx[l80.src_up].act, l80.wp, l80.scale, l80.shift, l81.wp, l81.scale,
+        L.block32_fused_fwd(self._input_of(l80, l80.src), self._input_of(l80, l80.src_up), l80.wp, l80.scale, l80.shift, l81.wp, l81.scale,
                             l81.shift, l82.act, post=1, wC=l82.wp, biasC=l82.bias, alpha=cfg.ALPHA)
 
     def _forward_prefix(self, upto: int, is_training: bool) -> None:
@@ -811,9 +811,18 @@ class YOLONet(object):
         """``sess.run(net.logits)``: returns (predictions, detections, mask_pos) with
         predictions = [yolov3_3, yolov3_2, yolov3_1] raw logits [B,g,g,3,5+C] (f32),
         detections [B,30,6], mask_pos [B,S/2,S/2,k*k] (yolo/yolo3_net_pos.py:353-357,463)."""
-        self._set_inputs(images, clip_window)
-        self._forward_layers(is_training)
-        self._detect(float(np.asarray(det_thresh).reshape(-1)[0]))
+        # backbone_pair: the caller's images are half 0 of the 2B-image backbone pass; the trainable layers, the clip
+        # windows and the outputs must be that half's too, whatever half the training loop stopped at
+        prev_half = self._half
+        if self.pair and prev_half != 0:
+            self._use_half(0)
+        try:
+            self._set_inputs(images, clip_window)
+            self._forward_layers(is_training)
+            self._detect(float(np.asarray(det_thresh).reshape(-1)[0]))
+        finally:
+            if self.pair and prev_half != 0:
+                self._use_half(prev_half)
         preds = [self.by_idx[i].act.view(self.B, self.by_idx[i].Ho, self.by_idx[i].Wo, 3, 5 + self.num_class)
                  for i in (75, 67, 59)]
         return preds, self.detections, self.by_idx[82].act
@@ -1454,6 +1463,8 @@ class YOLONet(object):
             self.run_program()
             return self.total_loss() if want_loss else None
         if self.pair:
+            if self.dp is not None:
+                raise L.DisyoloError("backbone_pair is a single-GPU option (no gradient exchange point in its step)")
             self.compute_losses(det_thresh, 1 if self._half == 0 else self._pair_P + 1)
             self.backward(sweep=True)
             self.optimizer_step()

@@ -29,34 +29,31 @@ from . import config as cfg
 from .checkpoint import restore_net, save_net
 
 
-class Timer(object):
-    """utils/timer.py:3-37"""
+class Timer:
+    """Wall-clock bookkeeping for the log line of Solver.train: mean seconds per tic/toc interval and an ETA from the
+    time since construction (the role utils/timer.py plays for train_yolo3_mask.py:143-195)."""
 
     def __init__(self):
-        self.init_time = time.time()
-        self.total_time = 0.0
-        self.calls = 0
-        self.start_time = 0.0
-        self.diff = 0.0
-        self.average_time = 0.0
-        self.remain_time = 0.0
+        self._born = time.perf_counter()
+        self._t0 = self._born
+        self._sum, self._n = 0.0, 0
 
-    def tic(self):
-        self.start_time = time.time()
+    def tic(self) -> None:
+        self._t0 = time.perf_counter()
 
-    def toc(self, average=True):
-        self.diff = time.time() - self.start_time
-        self.total_time += self.diff
-        self.calls += 1
-        self.average_time = self.total_time / self.calls
-        return self.average_time if average else self.diff
+    def toc(self) -> float:
+        self._sum += time.perf_counter() - self._t0
+        self._n += 1
+        return self.average_time
 
-    def remain(self, iters, max_iters):
-        if iters == 0:
-            self.remain_time = 0
-        else:
-            self.remain_time = (time.time() - self.init_time) * (max_iters - iters) / iters
-        return str(datetime.timedelta(seconds=int(self.remain_time)))
+    @property
+    def average_time(self) -> float:
+        return self._sum / max(self._n, 1)
+
+    def remain(self, done: int, total: int) -> str:
+        """h:mm:ss left if the remaining iterations go at the pace of the ``done`` ones so far"""
+        left = 0 if done <= 0 else (time.perf_counter() - self._born) / done * max(total - done, 0)
+        return str(datetime.timedelta(seconds=int(left)))
 
 
 def scheduled_learning_rate(step: int) -> float:

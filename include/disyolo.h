@@ -130,7 +130,7 @@ int disyolo_conv_first_fwd(const float* images, const float* w_hwio, const float
                            float alpha, void* stream);
 
 /* conv1 + conv2 in one launch when both run in inference mode (locked / inference net): act2 = leaky(bn2(conv3x3 stride 2
- * (leaky(bn1(conv3x3(images)))))), yolo/yolo3_net_pos.py:159-169 -- conv1's output (one consumer, the largest tensor of the
+ * (leaky(bn1(conv3x3(images)))))), conv_bn 'convolutional1' + 'convolutional2', yolo/yolo3_net_pos.py:159-167 -- conv1's output (one consumer, the largest tensor of the
  * network) is never written.  images f32 NHWC [B,H,W,3]; w1 f32 HWIO [3,3,3,32]; w2 bf16 packed [64][9*32] (pack_weights);
  * folded BN scale / shift per layer; y bf16 [B,H/2,W/2,64].  conv1 runs on the bf16 matrix cores with hi/lo-split operands
  * (relative error 2^-16 per product against exact f32, before the rounding to bf16).  disyolo_conv12_fused_ok: 1 when the
@@ -143,9 +143,9 @@ int disyolo_conv12_fused_fwd(const float* images, const float* w1_hwio, const fl
 /* The two HBM-bound [1x1 -> 32] -> [3x3 32 -> 64] chains of the half-resolution maps in one launch each, batch norms in
  * inference mode (folded scale / shift, leaky alpha); the 32- and 64-channel intermediates stay on chip:
  *   post 0  (C0 = 64, C1 = 0): y bf16 [B,H,W,64] = leaky(bnB(conv3x3(leaky(bnA(conv1x1(x0)))))) + x0 -- the first residual
- *           block, yolo/yolo3_net_pos.py:172-189;
+ *           block (conv_bn 'convolutional3' + res_conv_bn 'convolutional4'), yolo/yolo3_net_pos.py:169-176;
  *   post 1  (C0 = 64, C1 = 32): y f32 [B,H,W,9] = conv1x1(leaky(bnB(conv3x3(leaky(bnA(conv1x1([x0, up2(x1)]))))))) + biasC -- the
- *           mask head, yolo/yolo3_net_pos.py:455-476; x1 bf16 [B,H/2,W/2,32] is read at (y/2, x/2).
+ *           mask head (conv_bn 'convolutional80', 'convolutional81', conv 'convolutional82'), yolo/yolo3_net_pos.py:404-412; x1 bf16 [B,H/2,W/2,32] is read at (y/2, x/2).
  * x0 bf16 NHWC; wA packed [32][C0+C1], wB packed [64][9*32], wC packed [9][64] (pack_weights).  _ok: 1 when covered
  * (those two shapes, H a multiple of 8, W of 16). */
 int disyolo_block32_fused_ok(int B, int H, int W, int C0, int C1, int post);
@@ -155,7 +155,7 @@ int disyolo_block32_fused_fwd(const void* x0, const void* x1, int C0, int C1, co
 
 /* A residual block of the quarter-resolution maps in one launch, batch norms in inference mode: y bf16 [B,H,W,128] =
  * leaky(bnB(conv3x3(leaky(bnA(conv1x1(x)))))) + x with x bf16 [B,H,W,128], wA packed [64][128], wB packed [128][9*64]
- * (yolo/yolo3_net_pos.py:194-211, conv6+7 and conv8+9); the 64-channel intermediate stays in LDS.  _ok: C0 == 128, H a
+ * (conv_bn + res_conv_bn, yolo/yolo3_net_pos.py:184-201, conv6+7 and conv8+9); the 64-channel intermediate stays in LDS.  _ok: C0 == 128, H a
  * multiple of 8, W of 16. */
 int disyolo_block64_fused_ok(int B, int H, int W, int C0);
 int disyolo_block64_fused_fwd(const void* x, const void* wA, const float* scaleA, const float* shiftA, const void* wB,

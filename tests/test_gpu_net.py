@@ -463,6 +463,44 @@ def test_backbone_pair_steps_match_plain_steps(dev, recorded):
         assert float((a - b).abs().max()) <= 4.5e-4 + 1e-3 * float(a.abs().max()), name     # (Adam: |step| <= lr = 1e-4 each)
 
 
+@pytest.mark.parametrize("recorded", [False, True])
+def test_backbone_pair_inference_after_odd_and_even_steps(dev, recorded):
+    """forward(is_training=False) / evaluation() on a backbone_pair net (what Solver.validate calls between steps): the
+    caller's B images are half 0 of the 2B-image backbone pass, and every trainable layer, fused launch, clip window and
+    output must be that half's whatever half the training loop stopped at.  Against a plain net holding the same
+    variables, after an even step (the loop is about to train half 1) and after an odd one.  ADVICE r3: the fused
+    mask head read the 2B-image skip tensor and wrote 2B images into a B-image buffer."""
+    B, S = 2, 64
+    batches = [O.synthetic_batch(B, S, seed=90 + t) for t in range(4)]
+    val = O.synthetic_batch(B, S, seed=99)
+    pair = YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=1, seed=8, backbone_pair=True)
+    plain = make_net(dev, True, 1, B=B, S=S, seed=8)
+    guard = torch.full_like(pair.by_idx[82].act, 7.0)       # allocated right behind the net's buffers
+    if recorded:
+        pair.build_program(det_thresh=0.1)
+    for t in range(2):
+        pair.train_step((batches[2 * t], batches[2 * t + 1]) if t % 2 == 0 else None, det_thresh=0.1)
+        plain.load_state_dict(pair.state_dict())
+        p_pair, d_pair, m_pair = pair.forward(val["images"], val["clip_window"], [0.1], is_training=False)
+        p_pair = [x.clone() for x in p_pair]; d_pair = d_pair.clone(); m_pair = m_pair.clone()
+        p_plain, d_plain, m_plain = plain.forward(val["images"], val["clip_window"], [0.1], is_training=False)
+        torch.cuda.synchronize()
+        assert m_pair.shape == m_plain.shape and m_pair.shape[0] == B
+        for a, b in zip(p_pair + [m_pair], list(p_plain) + [m_plain]):
+            err = float((a.double() - b.double()).norm() / b.double().norm())
+            assert err < 5e-3, (t, err)        # the 2B backbone pass may pick other tiles: f32 summation order only
+        eb = pair.evaluation(val["images"], val["clip_window"], [0.1])
+        ea = plain.evaluation(val["images"], val["clip_window"], [0.1])
+        for b in range(B):
+            assert eb[0][b].shape == ea[0][b].shape
+            np.testing.assert_allclose(eb[0][b], ea[0][b], rtol=2e-2, atol=2e-3)
+        assert pair._half == (0 if recorded else (t + 1) % 2)      # the training loop's half is restored
+    assert bool((guard == 7.0).all())
+    with pytest.raises(L.DisyoloError):
+        from disyolo_amd import dp as DP
+        DP.enable_data_parallel(pair)
+
+
 def test_device_shuffle_produces_fresh_uniform_permutations(dev):
     B = 64
     pd = torch.zeros(B, 30, dtype=torch.int32, device=dev)

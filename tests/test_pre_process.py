@@ -169,9 +169,10 @@ def test_load_verify_contour_builds_the_cache(tmp_path):
 
 
 def test_reference_sample_data_golden_and_synthetic_replay():
-    """tests/golden/pre_process_sample.json = load_verify_contour run on the reference's own data/train_sample (four
-    images, six class masks, 00044.xml with four 'merge' boxes; tools/make_golden_pre_process.py, build container
-    only -- the JPEGs do not travel).  (1) what the file records must be self-consistent: the contour tracer's outer
+    """A REGRESSION fixture, not a pin: tests/golden/pre_process_sample.json is what THIS package's load_verify_contour
+    produced on the reference's data/train_sample -- the reference's pre_process.py needs cv2 and never ran, so nothing
+    here is reference output (cv2.findContours parity stays unpinned).  (Four images, six class masks, 00044.xml with
+    four 'merge' boxes; tools/make_golden_pre_process.py, build container only -- the JPEGs do not travel.)  (1) what the file records must be self-consistent: the contour tracer's outer
     borders / holes equal scipy.ndimage's independent component counts of the same masks, and the four merge boxes
     of 00044.xml became four merged instances (three rebar pieces in the first box).  (2) replay: synthetic masks
     with one small blob at every recorded instance centroid go through regions_from_masks + merge_regions with the
