@@ -647,20 +647,33 @@ class YOLONet(object):
             L.set_lane(0)
             L.lane_sync(1, 0)
 
+    def _fold_trainable(self, *idxs) -> None:
+        """a fused launch reads scale / shift of its layers directly: in a training net evaluated with is_training=False a
+        trainable layer's pair still holds the last step's BATCH statistics -- fold its moving statistics first (what
+        _forward_layer does for the layer-by-layer path)"""
+        for i in idxs:
+            l = self.by_idx[i]
+            if self.training and not l.lock and l.kind != "lin":
+                L.bn_fold(l.gamma, l.beta, l.mm, l.mv, cfg.BN_EPSILON, l.scale, l.shift)
+
     def _forward_first_two(self) -> None:
         l1, l2 = self.by_idx[1], self.by_idx[2]
+        self._fold_trainable(1, 2)
         L.conv12_fused_fwd(self.images, l1.w, l1.scale, l1.shift, l2.wp, l2.scale, l2.shift, l2.act, alpha=cfg.ALPHA)
 
     def _forward_block34(self) -> None:
         l2, l3, l4 = self.by_idx[2], self.by_idx[3], self.by_idx[4]
+        self._fold_trainable(3, 4)
         L.block32_fused_fwd(self._input_of(l3, 2), None, l3.wp, l3.scale, l3.shift, l4.wp, l4.scale, l4.shift, l4.act, post=0, alpha=cfg.ALPHA)
 
     def _forward_block64(self, i3: int) -> None:
         la, lb = self.by_idx[i3 - 1], self.by_idx[i3]
+        self._fold_trainable(i3 - 1, i3)
         L.block64_fused_fwd(self._input_of(la, la.src), la.wp, la.scale, la.shift, lb.wp, lb.scale, lb.shift, lb.act, alpha=cfg.ALPHA)
 
     def _forward_mask_head(self) -> None:
         l80, l81, l82 = self.by_idx[80], self.by_idx[81], self.by_idx[82]
+        self._fold_trainable(80, 81)
         L.block32_fused_fwd(self._input_of(l80, l80.src), self._input_of(l80, l80.src_up), l80.wp, l80.scale, l80.shift, l81.wp, l81.scale,
                             l81.shift, l82.act, post=1, wC=l82.wp, biasC=l82.bias, alpha=cfg.ALPHA)
 

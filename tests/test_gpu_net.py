@@ -501,6 +501,28 @@ def test_backbone_pair_inference_after_odd_and_even_steps(dev, recorded):
         DP.enable_data_parallel(pair)
 
 
+@pytest.mark.parametrize("stage", [1, 2])
+def test_training_net_evaluated_between_steps_matches_an_inference_net(dev, stage):
+    """Solver.validate (train_yolo3_mask.py:164-178) runs sess.run(net.evaluation) on the TRAINING graph between steps:
+    every layer then normalises with its moving statistics.  A training net after two steps against an inference net
+    holding the same variables -- the fused launches (conv1+2, residual blocks, mask head) read scale / shift
+    directly, and after a step those of a trainable layer hold the batch statistics (round 4: the fused mask head
+    used them)."""
+    B, S = 2, 64
+    tnet = make_net(dev, True, stage, B=B, S=S, seed=12)
+    for t in range(2):
+        tnet.train_step(O.synthetic_batch(B, S, seed=120 + t), det_thresh=0.1)
+    inet = make_net(dev, False, stage, B=B, S=S, seed=1)
+    inet.load_state_dict(tnet.state_dict())
+    val = O.synthetic_batch(B, S, seed=129)
+    assert sorted(tnet._fusion_plan(False, 1, 82)) == sorted(inet._fusion_plan(False, 1, 82))
+    pa, da, ma = tnet.forward(val["images"], val["clip_window"], [0.1], is_training=False)
+    pb, db, mb = inet.forward(val["images"], val["clip_window"], [0.1], is_training=False)
+    torch.cuda.synchronize()
+    for a, b in zip(list(pa) + [ma, da], list(pb) + [mb, db]):
+        assert torch.equal(a, b)
+
+
 def test_device_shuffle_produces_fresh_uniform_permutations(dev):
     B = 64
     pd = torch.zeros(B, 30, dtype=torch.int32, device=dev)
