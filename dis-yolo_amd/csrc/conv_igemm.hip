@@ -15,97 +15,12 @@
 // bank-conflict free (see DESIGN.md "LDS layout").
 #include <utility>
 #include "common.h"
+#include "conv_common.h"
 #include "runtime.h"
 
+using namespace dyconv;
+
 namespace {
-
-struct ConvParams {
-  const bf16* x0;
-  const bf16* x1;
-  const bf16* w;
-  const float* scale;
-  const float* shift;
-  const bf16* residual;
-  void* y;
-  float* stats;
-  const bf16* bn_x;          // DISYOLO_CONV_BN_BWD_STATS (patch kernel): the target layer's pre-BN conv output ...
-  const float* bn_scale;     // ... its scale / shift / batch mean / rstd ...
-  const float* bn_shift;
-  const float* bn_mean;
-  const float* bn_rstd;
-  float* bn_part;            // ... and the partial sums [tilesM][Cout][2] this launch writes
-  float bn_alpha;
-  int B, H, W, C0, C1, Cin;
-  int Ho, Wo, Cout;
-  int ks, stride, pad_t, pad_l, dmask, dshift;
-  int M, K, nk;
-  unsigned bytes0, bytes1, bytesw;
-  int tilesM, tilesN;
-  int pcls, Mc, tilesMc;     // stride-2 data gradient by output-parity classes (GEMM tiles): see conv_igemm_kernel
-  int tapmask, d2s_c;        // stride-2 data gradient as a 2x2-tap conv over dy with a depth-to-space store (disyolo_dgrad_s2_quad)
-  int xcd_n;                 // GEMM tiles: an XCD's run of tiles walks the pixel tiles of a few channel tiles (weights > input)
-  int flags;
-  float alpha;
-};
-
-// swizzle of the 16-byte chunk index inside one LDS row: 64-byte rows (BK=32) use a 4-entry
-// table on (row>>2)&3, 128-byte rows (BK=64) XOR (row>>1)&7; both make the 16-lane groups of
-// a ds_read_b128 fragment read hit 16 distinct 16-byte bank slots (DESIGN.md "LDS layout")
-template <int BK>
-__device__ __forceinline__ int swz(int row, int chunk) {
-  if (BK == 32) return chunk ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3);
-  return chunk ^ ((row >> 1) & 7);
-}
-
-// 64-byte rows read at ANY row alignment (the patch kernel's tap-shifted pixel fragments): the
-// 4-entry table above is conflict-free only for fragments starting at a multiple of 16 rows;
-// XOR with 2*((row>>2)&1) is conflict-free for 16 consecutive rows from any start (the 8 tables
-// with that property, by exhaustive search, are all of this alternating form).
-__device__ __forceinline__ int swz_any(int row, int chunk) { return chunk ^ (((row >> 2) & 1) << 1); }
-
-// one LDS-DMA: 64 lanes x 16 B, buffer (descriptor + per-lane 32-bit byte offset) -> LDS
-// (wave-uniform base in M0 + lane*16).  Lanes whose offset is past the descriptor's range get
-// zeros written (hardware range check; probed on gfx950 with tools/probe_lds_dma.hip): that is
-// the zero padding of the SAME conv, the ragged M/N edges and the odd taps of the stride-2
-// data gradient, with no branch and no pointer select.  Issued through inline asm so hipcc
-// does not see a pending LDS write and drain vmcnt(0) before every fragment read; completion
-// is tracked by the counted s_waitcnt vmcnt(N) in the main loop (an LDS-DMA has no VGPR
-// destination, so it is register-safe).  Nothing else in this kernel uses M0.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned OOB = 0x80000000u;
-// address = descriptor base + voff (per lane) + soff (wave-uniform SGPR); the range check
-// covers voff + soff (probed: tools/probe_lds_dma2.hip), so OOB lanes stay out of range.
-template <int LDS_IMM>
-__device__ __forceinline__ void dma16(unsigned voff, i32x4 srd, unsigned soff, unsigned lds_base) {
-  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-               :
-               : "v"(voff), "s"(srd), "s"(soff), "s"(lds_base + LDS_IMM)
-               : "memory");
-}
-// m / d and m % d for 0 <= m < 2^24 via one float division and a +-1 fix-up
-__device__ __forceinline__ void divmod_small(int m, int d, int& q, int& r) {
-  q = (int)(__fdividef((float)m, (float)d));
-  r = m - q * d;
-  if (r < 0) {
-    --q;
-    r += d;
-  } else if (r >= d) {
-    ++q;
-    r -= d;
-  }
-}
-__device__ __forceinline__ i32x4 make_srd(const void* base, unsigned bytes) {
-  i32x4 r;
-  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)base);
-  r[1] = __builtin_amdgcn_readfirstlane((int)((size_t)base >> 32)) & 0xffff;
-  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
-  r[3] = 0x00020000;
-  return r;
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // KS = filter size (1 or 3) is a compile-time parameter: the 1x1 instance drops the tap cursor
 // and the per-tap offset refresh altogether (and shows up as its own row in a profile).
@@ -571,8 +486,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
           s += red[(w_ * BN + nl) * 2 + 0];
           s2 += red[(w_ * BN + nl) * 2 + 1];
         }
-        p.stats[((size_t)mt * p.Cout + n) * 2 + 0] = s;
-        p.stats[((size_t)mt * p.Cout + n) * 2 + 1] = s2;
+        stats_out(p, mt, n, s, s2);
       }
     }
   }
@@ -704,46 +618,10 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
 // wave holds up to FW of them x NI channel fragments.  LDS per stage: halo [pixels][32 ch] +
 // weights [tap][BN][32], 64-byte rows, 16-byte chunks XOR-swizzled as in the GEMM kernel;
 // 2 stages (compute slice c while slice c+1 lands).
-// batch-norm backward sums of one stored 16-byte chunk (8 channels of one pixel): g = dy*act'(z), xhat
-struct BnBwdLane {
-  float sc[8], sh[8], mu[8], rs[8], s1[8], s2[8];
-  __device__ __forceinline__ void init(const ConvParams& p, int n, bool ok) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      sc[k] = ok ? p.bn_scale[n + k] : 0.f;
-      sh[k] = ok ? p.bn_shift[n + k] : 0.f;
-      mu[k] = ok ? p.bn_mean[n + k] : 0.f;
-      rs[k] = ok ? p.bn_rstd[n + k] : 0.f;
-      s1[k] = s2[k] = 0.f;
-    }
-  }
-  __device__ __forceinline__ void add(const uint4& dy, const uint4& x, float alpha) {
-    float g[8], vx[8];
-    unpack8(dy, g);
-    unpack8(x, vx);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float z = vx[k] * sc[k] + sh[k];
-      const float gg = g[k] * (z > 0.f ? 1.f : alpha);
-      const float xh = (vx[k] - mu[k]) * rs[k];
-      s1[k] += gg;
-      s2[k] += gg * xh;
-    }
-  }
-  // sum over the lanes that hold the same chunk column: lane ids equal modulo CPR8
-  template <int CPR8>
-  __device__ __forceinline__ void reduce() {
-#pragma unroll
-    for (int o = CPR8; o < 64; o <<= 1) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        s1[k] += __shfl_xor(s1[k], o, 64);
-        s2[k] += __shfl_xor(s2[k], o, 64);
-      }
-    }
-  }
-};
 
+#ifdef HALO_ABL_NOMFMA
+__device__ __forceinline__ void abl_keep(const bf16x8& a, const bf16x8& b, f32x4& c) { asm volatile("" ::"v"(a), "v"(b), "v"(c)); }
+#endif
 template <int NW, int FW, int NI>
 __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH, int PW, int tilesY, int tilesX) {
 #ifdef HALO_PROBE
@@ -815,7 +693,10 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
   // DMA i of a slice: i < AIM halo, else weights.  The first slice is issued in one go; the
   // following ones are spread over the 9 taps of the slice being multiplied, so a wave's DMA
   // issue (~60 cycles each) overlaps its own MFMAs instead of preceding them.
-  constexpr int NDMA = AIM + BIM, DPT = (NDMA + 4) / 5;   // the next slice's DMAs go out during the first 5 taps: they have 4 taps left to land
+#ifndef HALO_DMA_TAPS
+#define HALO_DMA_TAPS 5
+#endif
+  constexpr int NDMA = AIM + BIM, DPT = (NDMA + HALO_DMA_TAPS - 1) / HALO_DMA_TAPS;   // the next slice's DMAs go out during the first 5 taps: they have 4 taps left to land
   auto issue_one = [&]<int I>(std::integral_constant<int, I>, unsigned cs2 /* byte offset of the channel slice */, int stage) {
     if constexpr (I < NDMA) {
       const unsigned sbase = lds0 + stage * STB + wave * 1024;
@@ -881,16 +762,25 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
   auto load_frags = [&]<int TAP>(std::integral_constant<int, TAP>, const char* st) {
     constexpr int kh = TAP / 3, kw = TAP % 3, bi = TAP & 1;
 #pragma unroll
+#ifdef HALO_ABL_NOREAD      // (compile-time ablation, probe builds only: the fragments are never read)
+    for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(wfr[bi][j]));
+#pragma unroll
+    for (int t = 0; t < FW; ++t) asm volatile("" : "+v"(xfr[bi][t]));
+    (void)kh; (void)kw; (void)st;
+#else
     for (int j = 0; j < NI; ++j) wfr[bi][j] = *reinterpret_cast<const bf16x8*>(st + wb[j] + TAP * BN * 64);
 #pragma unroll
     for (int t = 0; t < FW; ++t) {
       const int hp = hp0[t] + kh * HW_ + kw;
       xfr[bi][t] = *reinterpret_cast<const bf16x8*>(st + hp * 64 + swz_any(hp, fchunk) * 16);
     }
+#endif
   };
   auto slice_body = [&]<bool DMA>(std::bool_constant<DMA>, int c) {
+#ifndef HALO_ABL_NOBAR
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // slice c has landed for everyone; everyone is done with slice c-1
+#endif
     asm volatile("" ::: "memory");
     const unsigned cs_next = (unsigned)(c + 1) * 64u;
     const int stage_next = (c + 1) & 1;
@@ -900,22 +790,22 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
       constexpr int bi = TAP & 1;
       if constexpr (TAP < 8) load_frags(std::integral_constant<int, TAP + 1>{}, st);
       __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise sinks the reads back next to their uses)
+#ifndef HALO_ABL_NODMA
       if constexpr (DMA) {
         [&]<int... D>(std::integer_sequence<int, D...>) {
           (issue_one(std::integral_constant<int, TAP * DPT + D>{}, cs_next, stage_next), ...);
         }(std::make_integer_sequence<int, DPT>{});
       }
+#endif
 #pragma unroll
       for (int t = 0; t < FW; ++t)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-#ifdef DY_PROBE
-          if (p.flags & 0x10000) {
-            asm volatile("" ::"v"(xfr[bi][t]), "v"(wfr[bi][j]));
-            continue;
-          }
-#endif
+#ifdef HALO_ABL_NOMFMA
+          abl_keep(xfr[bi][t], wfr[bi][j], acc[t][j]);
+#else
           acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[bi][j], xfr[bi][t], acc[t][j], 0, 0, 0);
+#endif
         }
     };
     [&]<int... T>(std::integer_sequence<int, T...>) {
@@ -981,8 +871,7 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
           s += red[(w_ * BN + nl) * 2 + 0];
           s2 += red[(w_ * BN + nl) * 2 + 1];
         }
-        p.stats[((size_t)mt * p.Cout + n) * 2 + 0] = s;
-        p.stats[((size_t)mt * p.Cout + n) * 2 + 1] = s2;
+        stats_out(p, mt, n, s, s2);
       }
     }
   }
@@ -1089,8 +978,7 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
             s += red[(w_ * BN + nl) * 2 + 0];
             s2 += red[(w_ * BN + nl) * 2 + 1];
           }
-          p.bn_part[((size_t)mt * p.Cout + n) * 2 + 0] = s;
-          p.bn_part[((size_t)mt * p.Cout + n) * 2 + 1] = s2;
+          bnpart_out(p, mt, n, s, s2);
         }
       }
     }
@@ -1397,8 +1285,7 @@ __global__ __launch_bounds__(NW * 64) void conv_stream_kernel(ConvParams p, int 
             s1 += red[(w_ * BN + nl) * 2 + 0];
             s2 += red[(w_ * BN + nl) * 2 + 1];
           }
-          p.stats[((size_t)mt * p.Cout + n) * 2 + 0] = s1;
-          p.stats[((size_t)mt * p.Cout + n) * 2 + 1] = s2;
+          stats_out(p, mt, n, s1, s2);
         }
       }
       __syncthreads();   // the scratch is wave 0's staging tile
@@ -1666,8 +1553,7 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(ConvParams p, int n
           a += red[(w_ * BN + nl) * 2 + 0];
           b2 += red[(w_ * BN + nl) * 2 + 1];
         }
-        p.stats[((size_t)blockIdx.x * p.Cout + nl) * 2 + 0] = a;
-        p.stats[((size_t)blockIdx.x * p.Cout + nl) * 2 + 1] = b2;
+        stats_out(p, blockIdx.x, nl, a, b2);
       }
     }
   }
@@ -1894,6 +1780,10 @@ int resolve_tile(int id, bool bk64, int K) {
 }
 int dispatch(int id, bool bk64, int variant, const ConvParams& p, hipStream_t s) {
   id = resolve_tile(id, bk64, p.K);
+#ifdef DY_ONLY_HALO   // kernel-probe builds (tools/build_probe.sh): only the patch kernels are instantiated
+  disyolo_set_error("conv: probe build without the GEMM tiles (tile id %d)", id);
+  return DISYOLO_E_ARG;
+#else
   switch (id) {
     case 13: return variant ? launch<64, 128, 2, 2, 64, 3, 2>(p, s) : launch<64, 128, 2, 2, 64, 2, 2>(p, s);
     case 14: return launch<96, 128, 2, 2, 64, 2, 2>(p, s);   // 3 stages x 2 groups would need 168 KiB
@@ -1912,6 +1802,7 @@ int dispatch(int id, bool bk64, int variant, const ConvParams& p, hipStream_t s)
     DY_TILE(12, 192, 128, 4, 2, 2, 3, 3, 4) // 8 waves of 48x64
     default: disyolo_set_error("conv: unknown tile id %d", id); return DISYOLO_E_ARG;
   }
+#endif
 }
 
 // Launcher heuristic = the consensus of the in-sequence autotuner (YOLONet.autotune, which
@@ -1991,7 +1882,9 @@ static int resolve_sel(const disyolo_conv_desc* d, int M, Patch* pt) {
   int sel = pick_tile(d, M);
   for (int guard = 0; guard < 3; ++guard) {
     const int id = sel & 0xff;
-    if (id == 21) {
+    if (id == 24 || id == 25) {
+      if (flat_ok(d, id, nullptr)) return sel;
+    } else if (id == 21) {
       if (stream1x1_ok(d)) return sel;
     } else if (id == 20) {
       if (stream_ok(d, pt)) return sel;
@@ -2008,7 +1901,7 @@ static int resolve_sel(const disyolo_conv_desc* d, int M, Patch* pt) {
 extern "C" int disyolo_conv2d_bn_bwd_stats_ok(const disyolo_conv_desc* d) {
   if (!d || (d->flags & DISYOLO_CONV_OUT_F32) || d->Cout % 8) return 0;
   const int id = resolve_sel(d, d->B * d->Ho * d->Wo, nullptr) & 0xff;
-  return id >= 16 && id < 20 ? 1 : 0;
+  return (id >= 16 && id < 20) || id == 24 || id == 25 ? 1 : 0;
 }
 
 extern "C" int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d) {
@@ -2016,6 +1909,10 @@ extern "C" int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d) {
   const int M = d->B * d->Ho * d->Wo;
   Patch pt;
   const int id = resolve_sel(d, M, &pt) & 0xff;
+  if (id == 24 || id == 25) {
+    FlatGeom g;
+    return flat_ok(d, id, &g) ? g.tilesM : DISYOLO_E_ARG;
+  }
   if (id == 21) return stream1x1_blocks(M);
   if (id >= 16) return d->B * (d->H / pt.ph) * (d->W / pt.pw);
   const int bm = tile_bm(id);
@@ -2036,6 +1933,15 @@ extern "C" int disyolo_conv2d_tile(const disyolo_conv_desc* d, int* bm, int* bn,
   if (!d) return DISYOLO_E_ARG;
   Patch pt;
   const int sel = resolve_sel(d, d->B * d->Ho * d->Wo, &pt);
+  if ((sel & 0xff) == 24 || (sel & 0xff) == 25) {
+    FlatGeom g;
+    if (!flat_ok(d, sel & 0xff, &g)) return DISYOLO_E_ARG;
+    if (bm) *bm = g.bm;
+    if (bn) *bn = g.bn;
+    if (bk) *bk = 32;
+    if (stages) *stages = g.stages;
+    return sel & 0xff;
+  }
   if ((sel & 0xff) == 21) {
     if (bm) *bm = 32;
     if (bn) *bn = d->Cout <= 16 ? 16 : (d->Cout <= 32 ? 32 : 64);
@@ -2158,7 +2064,7 @@ extern "C" int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream) {
     DY_REQUIRE(d->bn_x && d->bn_scale && d->bn_shift && d->bn_mean && d->bn_rstd && d->bn_partials,
                "conv: BN_BWD_STATS flag with a null bn_* pointer");
     DY_REQUIRE(disyolo_conv2d_bn_bwd_stats_ok(d) == 1,
-               "conv: BN_BWD_STATS needs the patch kernel (tile 16-18 on a shape it covers), bf16 output, Cout %% 8 == 0");
+               "conv: BN_BWD_STATS needs a patch kernel (tile 16-18, 24, 25 on a shape it covers), bf16 output, Cout %% 8 == 0");
     p.bn_x = (const bf16*)d->bn_x; p.bn_scale = d->bn_scale; p.bn_shift = d->bn_shift; p.bn_mean = d->bn_mean;
     p.bn_rstd = d->bn_rstd; p.bn_part = d->bn_partials; p.bn_alpha = d->bn_alpha;
   }
@@ -2184,8 +2090,12 @@ extern "C" int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream) {
   Patch pt;
   const int sel = resolve_sel(d, p.M, &pt);
   switch (sel & 0xff) {
+    case 24:
+    case 25: return launch_flat(p, sel & 0xff, s);
+#ifndef DY_ONLY_HALO
     case 21: return launch_stream1x1(p, s);
     case 20: return launch_stream(p, pt, s);
+#endif
     case 16: return launch_halo<8, 3, 4>(p, pt, s);
     case 18: return launch_halo<8, 3, 2>(p, pt, s);
     case 17: return launch_halo<4, 3, 4>(p, pt, s);

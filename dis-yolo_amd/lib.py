@@ -329,7 +329,7 @@ def conv_shape_key(d: ConvDesc):
 
 # shape key -> tile code, filled by ConvTuner (YOLONet.autotune); consulted by make_conv_desc
 TUNED: dict = {}
-TUNE_CANDIDATES = (3, 0x203, 6, 0x206, 2, 0x202, 0x204, 10, 12, 0x20c, 0x10c, 0x108, 0x20d, 16, 17, 18, 20, 21)
+TUNE_CANDIDATES = (3, 0x203, 6, 0x206, 2, 0x202, 0x204, 10, 12, 0x20c, 0x10c, 0x108, 0x20d, 16, 17, 18, 20, 21, 24, 25)
 
 
 class ConvTuner:
@@ -453,7 +453,9 @@ def conv2d_fwd(d: ConvDesc) -> None:
     if TIMER is not None:
         if not hasattr(d, "_tname"):
             tid, bm, bn, bk, st = conv2d_tile(d)
-            if tid == 21:
+            if tid in (24, 25):
+                d._tname = "conv_flat_kernel<%s,2,%d>" % ("2,3,2,1" if tid == 24 else "4,3,1,2", st)
+            elif tid == 21:
                 d._tname = "conv1x1_stream_kernel<%d>" % (bn // 16)
             elif tid == 20:
                 d._tname = "conv_stream_kernel<8,3,4>"

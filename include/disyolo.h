@@ -48,15 +48,15 @@ enum {
   DISYOLO_CONV_OUT_F32 = 2,     /* y is f32 (head logits / score maps), else bf16    */
   DISYOLO_CONV_STATS = 4,       /* also emit per-channel (sum, sum of squares) of the
                                    raw accumulators into `stats` (training BN, :90)  */
-  DISYOLO_CONV_BN_BWD_STATS = 8 /* y is the (now final) gradient wrt the OUTPUT of a batch-
+  DISYOLO_CONV_BN_BWD_STATS = 8,/* y is the (now final) gradient wrt the OUTPUT of a batch-
                                    normalised layer: also emit that layer's batch-norm
                                    backward sums, per channel over this block's pixels,
                                    (sum g, sum g*xhat) with g = y*act'(bn_x*bn_scale+bn_shift),
                                    xhat = (bn_x-bn_mean)*bn_rstd, from the bf16 values
                                    stored to y, into `bn_partials` -- the column reduction
                                    disyolo_bn_act_bwd would otherwise start with.  Only the
-                                   3x3 patch kernel has this epilogue (tile ids 16-18:
-                                   disyolo_conv2d_bn_bwd_stats_ok tells), bf16 y,
+                                   3x3 patch kernels have this epilogue (tile ids 16-18, 24,
+                                   25: disyolo_conv2d_bn_bwd_stats_ok tells), bf16 y,
                                    Cout % 8 == 0 (TF autodiff of :68-107)                */
 };
 

@@ -83,6 +83,15 @@ CASES = [
     (3, 9, 9, 256, 256, 3, 1, 16),         # 9x9 patch = whole image, 6 of 24 fragment slots used
     (2, 18, 18, 64, 128, 3, 1, 18),        # patch kernel, 32 output channels per block
     (1, 18, 18, 96, 72, 3, 1, 18),         # ... ragged channel tile (72 = 2 x 32 + 8), three K slices
+    (2, 18, 18, 64, 128, 3, 1, 24),        # flat-frame patch kernel, 32x32x16 MFMA: 192 x 64 tiles, two K slices (two stages)
+    (8, 18, 18, 128, 128, 3, 1, 24),       # ... four slices on three stages, 16 M tiles (the last one nearly empty)
+    (3, 9, 11, 96, 64, 3, 1, 24),          # ... three slices, H != W, frame shorter than two tiles
+    (1, 36, 36, 160, 192, 3, 1, 24),       # ... five slices (three-stage loop leaves mid-unroll), P = 37
+    (2, 36, 36, 64, 128, 3, 1, 25),        # 384 x 64 tiles (3x2 fragments per wave)
+    (1, 26, 52, 192, 64, 3, 1, 25),        # ... six slices, P = 53
+    (1, 72, 72, 64, 64, 3, 1, 25),         # ... P = 73: nine DMA pieces per wave
+    (1, 20, 20, 32, 64, 3, 2, 24),         # stride 2 / 32 input channels: not covered, falls back
+    (2, 18, 18, 64, 72, 3, 1, 24),         # Cout not a multiple of 64: falls back
 ]
 
 
@@ -162,6 +171,38 @@ def test_conv_halo_residual_f32_and_pads(dev, tile):
     L.conv2d_fwd(d)
     torch.cuda.synchronize()
     check(y, before + O.conv2d_same(x, w, 1), 2.0 ** -7, 2e-3)
+
+
+@pytest.mark.parametrize("tile", [24, 25])
+def test_conv_flat_residual_accumulate_and_integer_identity(dev, tile):
+    """flat-frame patch kernels: residual add, the data-gradient use (y += conv through the residual pointer), and
+    -- on integer-valued operands, where every summation order is exact -- the bit-identical result of a GEMM tile"""
+    g = torch.Generator().manual_seed(170 + tile)
+    B, H, W, Cin, Cout = 3, 18, 36, 128, 128
+    x = bf16r(torch.randn(B, H, W, Cin, generator=g))
+    w = bf16r(torch.randn(3, 3, Cin, Cout, generator=g) / 34)
+    res = bf16r(torch.randn(B, H, W, Cout, generator=g))
+    xd, wd = x.to(torch.bfloat16).to(dev), pack_ref(w).to(torch.bfloat16).to(dev)
+    y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=dev)
+    d = L.make_conv_desc(xd, wd, y, 3, 1, residual=res.to(torch.bfloat16).to(dev), leaky=True, tile=tile)
+    assert L.conv2d_tile(d)[0] == tile
+    L.conv2d_fwd(d)
+    torch.cuda.synchronize()
+    check(y, O.leaky_relu(O.conv2d_same(x, w, 1), 0.1) + res, 2.0 ** -7, 1e-3)
+    d = L.make_conv_desc(xd, wd, y, 3, 1, pads=(1, 1), out_hw=(H, W), residual=y, tile=tile)   # y += conv
+    before = y.float().cpu().double()
+    L.conv2d_fwd(d)
+    torch.cuda.synchronize()
+    check(y, before + O.conv2d_same(x, w, 1), 2.0 ** -7, 2e-3)
+    xi = torch.randint(-3, 4, (B, H, W, Cin), generator=g).to(torch.bfloat16).to(dev)
+    wi = torch.randint(-2, 3, (Cout, 9 * Cin), generator=g).to(torch.bfloat16).to(dev)
+    outs = []
+    for t in (3, tile):
+        yi = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=dev)
+        L.conv2d_fwd(L.make_conv_desc(xi, wi, yi, 3, 1, tile=t))
+        torch.cuda.synchronize()
+        outs.append(yi.clone())
+    assert float(outs[0].float().abs().max()) > 50 and torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("B,H,W,Cout", [(2, 36, 36, 64), (3, 72, 48, 64), (1, 144, 144, 128), (2, 18, 90, 40)])
@@ -293,7 +334,7 @@ def test_conv_residual_and_fused_concat(dev):
     check(y, want, 2.0 ** -7, 1e-3)
 
 
-@pytest.mark.parametrize("tile", [0, 10, 12, 13, 14, 16, 17])
+@pytest.mark.parametrize("tile", [0, 10, 12, 13, 14, 16, 17, 24, 25])
 def test_conv_stats_and_bn_finalize(dev, tile):
     """training BN: stats epilogue + finalize == tf.nn.moments (population variance) and the
     moving-average update of yolo/yolo3_net_pos.py:90-98."""
@@ -627,6 +668,9 @@ BN_BWD_CASES = [
     (2, 18, 18, 96, 64, 18, True),         # 32 channels per block: one write-out round
     (3, 9, 9, 256, 256, 16, False),        # 9x9 patch = whole image, 6 of 24 fragment slots used
     (1, 36, 36, 64, 64, 16, True),         # four patches per image
+    (2, 18, 18, 64, 128, 24, True),        # flat-frame kernel, 192 x 64 tiles: every K group finishes a fragment
+    (8, 18, 18, 128, 64, 24, False),       # ... 16 M tiles
+    (2, 36, 36, 64, 128, 25, True),        # 384 x 64 tiles: K group g finishes channel half g
 ]
 
 
@@ -711,3 +755,4 @@ def test_bn_act_bwd_from_conv_partials_matches_the_plain_path(dev):
     assert ((outs[0][2] - outs[1][2]).abs() <= 2e-5 * mag + 1e-6).all()
     assert ((outs[0][1] - outs[1][1]).abs() <= 2e-5 * mag * 4 + 1e-6).all()
     check(outs[1][0], outs[0][0], 2.0 ** -7, 1e-4)
+

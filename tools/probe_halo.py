@@ -11,7 +11,7 @@ from disyolo_amd import lib as L
 
 dev = torch.device("cuda:0")
 bf = torch.bfloat16
-CASES = ((8, 36, 256, 512, 16, 8), (8, 18, 512, 1024, 18, 8), (8, 72, 128, 256, 16, 8), (8, 18, 512, 1024, 16, 8),
+CASES = ((8, 18, 512, 1024, 24, 8), (8, 36, 256, 512, 25, 8), (8, 36, 512, 256, 24, 8), (8, 36, 256, 512, 16, 8), (8, 18, 512, 1024, 18, 8), (8, 72, 128, 256, 16, 8), (8, 18, 512, 1024, 16, 8),
          # the 192x128 GEMM tile (8 waves of 48x64, two blocks per CU): training and inference batch
          (8, 72, 128, 256, 12, 8), (32, 72, 128, 256, 12, 8), (32, 36, 256, 512, 12, 8), (32, 18, 512, 1024, 12, 8))
 for (B, H, Cin, Cout, tile, nw) in CASES:
