@@ -123,39 +123,68 @@ __global__ __launch_bounds__(MW* NWV* KG * 64) void conv_flat_kernel(ConvParams 
   const i32x4 srdx = make_srd(p.x0, p.bytes0);
   const i32x4 srdw = make_srd(p.w, p.bytesw);
 
-  // ---- DMA pieces of this wave: piece k = i * NWAVES + wave; k < HP: halo rows 16k .. 16k+15, else weight rows
+  // ---- DMA pieces of this wave: piece k = i * NWAVES + wave; k < HP: halo rows 16k .. 16k+15, else weight rows.
+  // The weight pieces' offsets come first (shifts only) and slice 0's weights are requested before the halo
+  // positions are decoded: the decode runs under the first fetch.
   const int npw = __builtin_amdgcn_readfirstlane(NP > wave ? (NP - wave + NWAVES - 1) / NWAVES : 0);
   unsigned d_off[FLAT_DMAX];
 #pragma unroll
   for (int i = 0; i < FLAT_DMAX; ++i) {
     const int k = i * NWAVES + wave;
-    const int rr = k * 16 + (lane >> 2), cp = lane & 3;
     unsigned off = OOB;
-    if (k < HP) {
-      const int c = cp ^ ((rr >> 2) & 3);
-      int m;
-      if (rr < R && frame_decode(Q0 - (P + 1) + rr, FR, P, p.B, p.H, p.W, m)) off = (unsigned)m * (unsigned)p.C0 * 2u + c * 16;
-    } else if (k < NP) {
-      const int rb = rr - HP * 16;
+    if (k >= HP && k < NP) {
+      const int rb = (k - HP) * 16 + (lane >> 2), cp = lane & 3;
       const int c = cp ^ ((rb >> 2) & 3);
       const int tap = rb / BN, nl = rb - tap * BN;
       if (n0 + nl < p.Cout) off = ((unsigned)(n0 + nl) * (unsigned)p.K + (unsigned)(tap * p.Cin)) * 2u + c * 16;
     }
     d_off[i] = off;
   }
-  auto issue_one = [&]<int I>(std::integral_constant<int, I>, unsigned cs2, unsigned stage_base) {
+  auto issue_one = [&]<int I, int KIND = 0>(std::integral_constant<int, I>, unsigned cs2, unsigned stage_base,
+                                            std::integral_constant<int, KIND> = {}) {
     if constexpr (I < FLAT_DMAX) {
       if (I < npw) {
         const int k = I * NWAVES + wave;
-        dma16_rt(d_off[I], k < HP ? srdx : srdw, cs2, stage_base + (unsigned)k * 1024u);
+        if (KIND == 0 || (KIND == 1) == (k >= HP)) dma16_rt(d_off[I], k < HP ? srdx : srdw, cs2, stage_base + (unsigned)k * 1024u);
       }
     }
   };
-  auto issue_all = [&](int c, int stage) {
+  auto issue_all = [&]<int KIND>(std::integral_constant<int, KIND> kind, int c, int stage) {
     [&]<int... I>(std::integer_sequence<int, I...>) {
-      (issue_one(std::integral_constant<int, I>{}, (unsigned)c * 64u, lds0 + (unsigned)stage * STB), ...);
+      (issue_one(std::integral_constant<int, I>{}, (unsigned)c * 64u, lds0 + (unsigned)stage * STB, kind), ...);
     }(std::make_integer_sequence<int, FLAT_DMAX>{});
   };
+  const int nch = p.Cin >> 5;
+  issue_all(std::integral_constant<int, 1>{}, 0, 0);       // slice 0: weights
+  {
+    // halo pieces: frame position of this lane's row in piece slot 0, then +16*NWAVES rows per slot.  Decoded once
+    // (two float divisions), advanced by carries.  Positions are shifted by one image so that they are >= 0.
+    const int step = 16 * NWAVES;
+    int sa, sr;                                             // step = sa * P + sr
+    divmod_small(step, P, sa, sr);
+    sa = __builtin_amdgcn_readfirstlane(sa);
+    sr = __builtin_amdgcn_readfirstlane(sr);
+    const int rr0 = wave * 16 + (lane >> 2), cp = lane & 3;
+    int b, q, row, col;
+    divmod_small(Q0 - (P + 1) + rr0 + FR, FR, b, q);
+    divmod_small(q, P, row, col);
+    b -= 1;
+#pragma unroll
+    for (int i = 0; i < FLAT_DMAX; ++i) {
+      const int k = i * NWAVES + wave;
+      const int rr = rr0 + i * step;
+      if (k < HP) {
+        const int c = cp ^ ((rr >> 2) & 3);
+        const bool ok = rr < R && b >= 0 && b < p.B && row >= 1 && col >= 1;
+        if (ok) d_off[i] = (unsigned)((b * p.H + row - 1) * p.W + col - 1) * (unsigned)p.C0 * 2u + c * 16;
+      }
+      col += sr;
+      row += sa;
+      if (col >= P) { col -= P; ++row; }
+      while (row > p.H) { row -= p.H + 1; ++b; }
+    }
+  }
+  issue_all(std::integral_constant<int, 2>{}, 0, 0);       // slice 0: halo
 
   // ---- fragment read addresses
   const int rl = lane & 31, hl = lane >> 5;
@@ -191,11 +220,10 @@ __global__ __launch_bounds__(MW* NWV* KG * 64) void conv_flat_kernel(ConvParams 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
 
-  const int nch = p.Cin >> 5;
-  // prologue: the first ST-1 slices
+  // prologue: the slices up to ST-2 (slice 0 is already on its way)
 #pragma unroll
-  for (int c = 0; c < ST - 1; ++c)
-    if (c < nch) issue_all(c, c);
+  for (int c = 1; c < ST - 1; ++c)
+    if (c < nch) issue_all(std::integral_constant<int, 0>{}, c, c);
 
 #ifdef HALO_PROBE
   hp_t[1] = (long long)__builtin_amdgcn_s_memtime();
@@ -291,6 +319,35 @@ __global__ __launch_bounds__(MW* NWV* KG * 64) void conv_flat_kernel(ConvParams 
   char* xch = smem;
   char* stg = smem + XCH_BYTES + (unsigned)wave * STG_BYTES;
   float* red = reinterpret_cast<float*>(smem + XCH_BYTES + (unsigned)NWAVES * STG_BYTES);   // [NWAVES][NI*32][2]
+  float* scsh = red + NWAVES * NI * 32 * 2;                                                 // [2][BN]: scale, shift of this block's channels
+  // everything the finishing passes wait for is requested NOW, under the exchange of the K groups' sums: this block's
+  // scale / shift (-> LDS), the frame positions' output pixels, the residual values of the fragments this wave finishes
+  if (tid < BN) {
+    scsh[tid] = p.scale ? p.scale[n0 + tid] : 1.f;
+    scsh[BN + tid] = p.shift ? p.shift[n0 + tid] : 0.f;
+  }
+  int m_of[MI];
+#pragma unroll
+  for (int m = 0; m < MI; ++m) {
+    int mo;
+    const bool ok = frame_decode(Q0 + (mw * MI + m) * 32 + rl, FR, P, p.B, p.H, p.W, mo);
+    m_of[m] = ok ? mo : -1;
+  }
+  uint2 resv[MI][NI][4];
+  if (p.residual) {
+#pragma unroll
+    for (int m = 0; m < MI; ++m)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        if ((m * NI + j) % KG != kg) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          resv[m][j][q] = uint2{0u, 0u};
+          if (m_of[m] >= 0)
+            resv[m][j][q] = *reinterpret_cast<const uint2*>(p.residual + (size_t)m_of[m] * p.Cout + n0 + (nwv * NI + j) * 32 + q * 8 + hl * 4);
+        }
+      }
+  }
   if constexpr (KG > 1) {
 #pragma unroll
     for (int m = 0; m < MI; ++m)
@@ -325,14 +382,7 @@ __global__ __launch_bounds__(MW* NWV* KG * 64) void conv_flat_kernel(ConvParams 
       }
   }
 
-  // frame position -> output pixel of this lane, per M fragment
-  int m_of[MI];
-#pragma unroll
-  for (int m = 0; m < MI; ++m) {
-    int mo;
-    const bool ok = frame_decode(Q0 + (mw * MI + m) * 32 + rl, FR, P, p.B, p.H, p.W, mo);
-    m_of[m] = ok ? mo : -1;
-  }
+  if constexpr (KG == 1) __syncthreads();   // (scale / shift staged above; with K groups the exchange's barrier covers it)
 
   if (p.flags & DISYOLO_CONV_STATS) {
     // per-channel sum / sum of squares of the f32 results over this block's valid positions: lanes -> waves (LDS, fixed order)
@@ -407,18 +457,16 @@ __global__ __launch_bounds__(MW* NWV* KG * 64) void conv_flat_kernel(ConvParams 
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n = nf + q * 8 + hl * 4;
-        float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.scale) *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(p.scale + n);
-        if (p.shift) *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(p.shift + n);
+        const int nl = (nwv * NI + j) * 32 + q * 8 + hl * 4;       // channel within the block
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scsh + nl), sh = *reinterpret_cast<const f32x4*>(scsh + BN + nl);
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           v[r] = acc[m][j][4 * q + r] * sc[r] + sh[r];
           if (p.flags & DISYOLO_CONV_LEAKY) v[r] = leaky(v[r], p.alpha);
         }
-        if (p.residual && m_of[m] >= 0) {
-          const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)m_of[m] * p.Cout + n);
+        if (p.residual) {      // (positions outside the image hold zeros and are not stored)
+          const uint2 rr = resv[m][j][q];
           v[0] += __builtin_bit_cast(float, rr.x << 16);
           v[1] += __builtin_bit_cast(float, rr.x & 0xffff0000u);
           v[2] += __builtin_bit_cast(float, rr.y << 16);
@@ -494,7 +542,7 @@ bool flat_shape(int id, FlatShape* s) {
 }
 int flat_halo_pieces(int bm, int W) { return (bm + 2 * (W + 1) + 2 + 15) / 16; }
 size_t flat_epilogue_bytes(const FlatShape& s) {
-  return (size_t)s.xch_frags * 4096 + (size_t)s.nwaves * 32 * 80 + (size_t)s.nwaves * 64 * 2 * sizeof(float);
+  return (size_t)s.xch_frags * 4096 + (size_t)s.nwaves * 32 * 80 + (size_t)s.nwaves * 64 * 2 * sizeof(float) + 2 * 64 * sizeof(float);
 }
 constexpr size_t LDS_MAX = 160 * 1024;
 int flat_stages_env() {      // DISYOLO_FLAT_STAGES=2: two stages everywhere (A/B of the pipeline depth)
