@@ -5,12 +5,14 @@
 #include <stdio.h>
 #include "../../include/disyolo.h"
 
+#ifndef DY_HOST_ONLY   // (`make asan`: host-side sources as plain C++, no device types)
 typedef __bf16 bf16;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#endif
 #define DY_WAVE 64
 
 void disyolo_set_error(const char* fmt, ...);
@@ -33,6 +35,7 @@ void disyolo_set_error(const char* fmt, ...);
     }                                                                        \
   } while (0)
 
+#ifndef DY_HOST_ONLY
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
 __device__ __forceinline__ float bfbits2f(unsigned short b) {
   return __builtin_bit_cast(float, (unsigned)b << 16);
@@ -69,5 +72,7 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+#endif  // DY_HOST_ONLY
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -23,6 +23,7 @@ struct CmdList {
 thread_local CmdList* g_rec = nullptr;
 thread_local int g_lane = 0;
 
+#ifndef DY_HOST_ONLY
 __global__ __launch_bounds__(256) void add_bf16_kernel(const uint4* src, uint4* dst, int64_t nvec, int accumulate) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(256) void add_bf16_kernel(const uint4* src, uint4* 
     dst[i] = v;
   }
 }
+#endif
 }  // namespace
 
 // CRC-32C (Castagnoli), slicing-by-8: host helper of the checkpoint writer / reader (TensorFlow tensor
@@ -277,10 +279,15 @@ extern "C" int disyolo_cmdlist_run_ex(void* l, int first, int last, void* stream
 extern "C" int disyolo_add_bf16(const void* src, void* dst, int64_t n, int accumulate, void* stream) {
   DY_REQUIRE(src && dst && n > 0 && n % 8 == 0, "add_bf16: bad args");
   DY_RECORD_OR_RUN([=](void* s) { return disyolo_add_bf16(src, dst, n, accumulate, s); });
+#ifdef DY_HOST_ONLY      // (`make asan`: no device code in the host-only build)
+  (void)stream;
+  return DISYOLO_OK;
+#else
   int64_t g = (n / 8 + 255) / 256;
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(add_bf16_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst,
                      n / 8, accumulate);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
+#endif
 }

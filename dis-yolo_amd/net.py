@@ -17,6 +17,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import math
 import json
+import contextlib
 import os
 import sys
 import numpy as np
@@ -1437,9 +1438,17 @@ class YOLONet(object):
         self.dp.begin_step()
         # every recorded list owns its side lane: the bucket's all-reduce must be ordered after the
         # lane of the list that is running NOW (the pipelined step alternates between two lists)
-        side = self._side_streams.get(id(self._prog))
-        if side is None:
-            side = self._side_streams[id(self._prog)] = self._prog.side_stream(self.device)
+        cuda = self.device.type == "cuda"          # (a plan-only net on the CPU drives the same cut loop in tests/test_dp_gloo.py)
+        side = None
+        if cuda:
+            side = self._side_streams.get(id(self._prog))
+            if side is None:
+                side = self._side_streams[id(self._prog)] = self._prog.side_stream(self.device)
+
+        def on_lane(use_side: bool):
+            if not cuda:
+                return contextlib.nullcontext()
+            return torch.cuda.stream(side if use_side else torch.cuda.current_stream())
         pos, first = 0, True
         for idx, what in self._prog_marks:
             self._prog.run(pos, idx, fork=first, join=False)
@@ -1447,11 +1456,11 @@ class YOLONet(object):
             if isinstance(what, tuple):
                 # SyncBN: the per-channel sums of one layer, on the lane that produced them
                 _, t, lane = what
-                with torch.cuda.stream(side if (lane == 1 and self.use_side_lane) else torch.cuda.current_stream()):
+                with on_lane(lane == 1 and self.use_side_lane):
                     import torch.distributed as dist
                     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.dp.pg)
             else:
-                with torch.cuda.stream(side if self.use_side_lane else torch.cuda.current_stream()):
+                with on_lane(self.use_side_lane):
                     self.dp.fire(what)
             pos = idx
         self._prog.run(pos, self._bwd_end, fork=first, join=True)
