@@ -74,7 +74,7 @@ def box_fingerprint(dev, local_rank: int = 0):
         w = (torch.randn(512, 9 * 256, device=dev) * 0.02).to(bf)
         y = torch.empty(8, 36, 36, 512, dtype=bf, device=dev)
         d = L.make_conv_desc(x, w, y, 3, 1, tile=16)
-        src = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+        src = torch.empty(512 << 20, dtype=torch.uint8, device=dev)     # (beyond the 256 MB Infinity Cache: an HBM copy)
         dst = torch.empty_like(src)
 
         def timed(fn, n):
@@ -95,7 +95,7 @@ def box_fingerprint(dev, local_rank: int = 0):
         ms_copy = timed(lambda: dst.copy_(src), 20)
         fp["conv_36x36_256to512_3x3_B8_us"] = round(ms_conv * 1e3, 2)
         fp["conv_tflops"] = round(2.0 * 8 * 36 * 36 * 512 * 2304 / (ms_conv * 1e-3) / 1e12, 1)
-        fp["copy_64MB_GBps_read_plus_write"] = round(2 * (64 << 20) / (ms_copy * 1e-3) / 1e9, 1)
+        fp["copy_512MB_GBps_read_plus_write"] = round(2 * (512 << 20) / (ms_copy * 1e-3) / 1e9, 1)
         del x, w, y, src, dst
     except Exception as e:
         fp["micro_error"] = repr(e)[:120]
