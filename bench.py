@@ -49,7 +49,7 @@ def box_fingerprint(dev, local_rank: int = 0):
     """What this box is, so that a slow draw is recognisable from the line itself (boxes of the pool differ by 3-7 % on
     identical code): rocm-smi's clocks / power cap / partition modes, and a fixed micro-benchmark measured BEFORE the
     workload -- one MFMA-bound layer (36^2 256 -> 512 3x3 at B = 8, 24.5 GFLOP, the launcher's own tile) and one
-    64 MB device copy -- a few milliseconds of GPU time.  `normalise` in the headline's config uses nothing of this:
+    512 MB device copy -- a few milliseconds of GPU time.  `normalise` in the headline's config uses nothing of this:
     it is a label, not a correction."""
     import subprocess
     fp = {}
