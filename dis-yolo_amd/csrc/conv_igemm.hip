@@ -950,7 +950,7 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
         // the pixel of row r16 of this fragment lives in lane r16 (any cq) of m_of[t]
         const int m = __shfl(m_of[t], r16, 64);
         const int n = n0 + ch * 8;
-        if (m >= 0 && n < p.Cout) {
+        if (idx < 16 * CPR8 && m >= 0 && n < p.Cout) {      // (16 channels per block: the 32 chunks of a fragment fill half a round)
           const uint4 o = *reinterpret_cast<const uint4*>(sw + (t * 16 + r16) * ROWP + ch * 16);
           *reinterpret_cast<uint4*>(yo + (size_t)m * p.Cout + n) = o;
           if (bnb) bl.add(o, bx[t * RPF + it], p.bn_alpha);
@@ -1584,13 +1584,14 @@ Patch pick_patch(int H, int W, int max_frags, int max_halo) {
 }
 // halo tile ids: 16 = 8 waves x 3 fragments (up to 384 pixels: 18x18), 17 = 4 waves x 3
 // (up to 192 pixels: 9x18), both 64 output channels per block; 18 = as 16 with 32 output channels per block
-// (twice the blocks: the 18x18 maps, one patch per image, then give 256 blocks at 1024 channels)
+// (twice the blocks: the 18x18 maps, one patch per image, then give 256 blocks at 1024 channels); 19 = 16 output channels per
+// block (256 blocks at 512 channels: the data gradient of the 18^2 512 -> 1024 layers)
 bool halo_cfg(int id, int& nw, int& fw) {
-  if (id == 16 || id == 18) { nw = 8; fw = 3; return true; }
+  if (id == 16 || id == 18 || id == 19) { nw = 8; fw = 3; return true; }
   if (id == 17) { nw = 4; fw = 3; return true; }
   return false;
 }
-int halo_bn(int id) { return id == 18 ? 32 : 64; }
+int halo_bn(int id) { return id == 18 ? 32 : id == 19 ? 16 : 64; }
 bool halo_ok(const disyolo_conv_desc* d, int id, Patch* out) {
   int nw, fw;
   if (!halo_cfg(id, nw, fw)) return false;
@@ -2098,6 +2099,7 @@ extern "C" int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream) {
 #endif
     case 16: return launch_halo<8, 3, 4>(p, pt, s);
     case 18: return launch_halo<8, 3, 2>(p, pt, s);
+    case 19: return launch_halo<8, 3, 1>(p, pt, s);   // 16 channels per block: 256 blocks where Cout = 512 on one patch per image (18^2 1024 -> 512)
     case 17: return launch_halo<4, 3, 4>(p, pt, s);
     default: break;
   }

@@ -329,7 +329,7 @@ def conv_shape_key(d: ConvDesc):
 
 # shape key -> tile code, filled by ConvTuner (YOLONet.autotune); consulted by make_conv_desc
 TUNED: dict = {}
-TUNE_CANDIDATES = (3, 0x203, 6, 0x206, 2, 0x202, 0x204, 10, 12, 0x20c, 0x10c, 0x108, 0x20d, 16, 17, 18, 20, 21, 24, 25)
+TUNE_CANDIDATES = (3, 0x203, 6, 0x206, 2, 0x202, 0x204, 10, 12, 0x20c, 0x10c, 0x108, 0x20d, 16, 17, 18, 19, 20, 21, 24, 25)
 
 
 class ConvTuner:
@@ -460,7 +460,7 @@ def conv2d_fwd(d: ConvDesc) -> None:
             elif tid == 20:
                 d._tname = "conv_stream_kernel<8,3,4>"
             elif tid >= 16:
-                d._tname = "conv_halo_kernel<%d,3,%d>" % (4 if tid == 17 else 8, 2 if tid == 18 else 4)
+                d._tname = "conv_halo_kernel<%d,3,%d>" % (4 if tid == 17 else 8, 2 if tid == 18 else 1 if tid == 19 else 4)
             else:
                 d._tname = "conv_igemm_kernel<%d,%d,%d,%d,%d,%d,%d,%d>" % ((bm, bn) + _WAVES[tid] +
                                                                             (bk, st, d.ksize, 2 if tid >= 13 else 1))

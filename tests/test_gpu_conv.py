@@ -83,6 +83,8 @@ CASES = [
     (3, 9, 9, 256, 256, 3, 1, 16),         # 9x9 patch = whole image, 6 of 24 fragment slots used
     (2, 18, 18, 64, 128, 3, 1, 18),        # patch kernel, 32 output channels per block
     (1, 18, 18, 96, 72, 3, 1, 18),         # ... ragged channel tile (72 = 2 x 32 + 8), three K slices
+    (2, 18, 18, 64, 128, 3, 1, 19),        # patch kernel, 16 output channels per block
+    (1, 18, 18, 96, 72, 3, 1, 19),         # ... ragged channel tile (72 = 4 x 16 + 8)
     (2, 18, 18, 64, 128, 3, 1, 24),        # flat-frame patch kernel, 32x32x16 MFMA: 192 x 64 tiles, two K slices (two stages)
     (8, 18, 18, 128, 128, 3, 1, 24),       # ... four slices on three stages, 16 M tiles (the last one nearly empty)
     (3, 9, 11, 96, 64, 3, 1, 24),          # ... three slices, H != W, frame shorter than two tiles
@@ -144,7 +146,7 @@ def test_conv_out_f32_bias_small_n(dev):
         check(y, want, 1e-5, 1e-4 * float(want.abs().max()))
 
 
-@pytest.mark.parametrize("tile", [16, 17, 18])
+@pytest.mark.parametrize("tile", [16, 17, 18, 19])
 def test_conv_halo_residual_f32_and_pads(dev, tile):
     """patch kernel epilogue variants: residual add, f32 output with bias, and the data-gradient
     use (explicit pads, accumulate into an existing gradient through the residual pointer)"""
@@ -666,6 +668,7 @@ BN_BWD_CASES = [
     (2, 18, 18, 64, 128, 16, True),        # patch kernel, 8 waves
     (2, 18, 36, 64, 72, 17, False),        # 4 waves, ragged channel tile (72 = 64 + 8)
     (2, 18, 18, 96, 64, 18, True),         # 32 channels per block: one write-out round
+    (2, 18, 18, 96, 64, 19, True),         # 16 channels per block
     (3, 9, 9, 256, 256, 16, False),        # 9x9 patch = whole image, 6 of 24 fragment slots used
     (1, 36, 36, 64, 64, 16, True),         # four patches per image
     (2, 18, 18, 64, 128, 24, True),        # flat-frame kernel, 192 x 64 tiles: every K group finishes a fragment

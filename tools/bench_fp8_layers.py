@@ -38,3 +38,14 @@ for i in range(1, 53):
     l = nets["bf16"].by_idx[i]
     print("%-4d %-28s %9.1f %9.1f" % (i, "%dx%d %d->%d k%d s%d" % (l.H, l.W, l.cin, l.cout, l.k, l.stride), row[0], row[1]))
 print("total us: bf16 %.1f  fp8 %.1f" % (tot["bf16"], tot["fp8"]))
+# the whole backbone as the product runs it (bf16: fused launches for conv1+2 / the 288^2 and 144^2 residual blocks; fp8: layer by layer)
+for dt in ("bf16", "fp8"):
+    n = nets[dt]
+    for _ in range(3):
+        n._forward_prefix(52, False)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        n._forward_prefix(52, False)
+    e1.record(); torch.cuda.synchronize()
+    print("backbone conv1-52 as the product runs it, %s: %.1f us" % (dt, e0.elapsed_time(e1) / 20 * 1e3))
