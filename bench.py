@@ -391,6 +391,11 @@ def main():
                          "table profiles/tune_<workload>.json when there is one for this workload (the run is then "
                          "bit-reproducible box to box and its losses are a regression canary), else tune live; "
                          "'none': always tune live")
+    ap.add_argument("--overlap-tail", default="auto", choices=("auto", "on", "off"),
+                    help="single GPU, list executor: the recorded step leaves its side lane's tail (the optimizer sweeps of the "
+                         "slices that became final last, the last weight gradients) running into the next replay's locked-backbone "
+                         "forward, with per-tensor dependencies (YOLONet.build_program(overlap_tail=True)); bit-identical results. "
+                         "auto = on where it applies")
     ap.add_argument("--pair", action="store_true",
                     help="stage 1: the locked backbone runs once per TWO batches at batch size 2B (YOLONet backbone_pair), "
                          "the trainable part steps through the halves; an even number of steps, each on its own batch")
@@ -491,8 +496,12 @@ def main():
     pipe = args.stage == 1 and mode == "program" and args.pipeline == "on"
     if args.pipeline == "on" and not pipe:
         raise SystemExit("--pipeline on needs --stage 1 and --mode program")
+    overlap = (args.overlap_tail != "off" and mode == "program" and not use_dp and not args.pair and not pipe
+               and os.environ.get("DISYOLO_SIDE_LANE", "1") != "0")
+    if args.overlap_tail == "on" and not overlap:
+        raise SystemExit("--overlap-tail on needs one GPU, --mode program, no --pair / --pipeline")
     if mode != "eager":
-        net.build_program(graph=(mode == "graph"), pipeline_backbone=pipe)
+        net.build_program(graph=(mode == "graph"), pipeline_backbone=pipe, overlap_tail=overlap)
         if pipe:
             net.prime_pipeline()       # backbone of the first batch, outside the timed region
     if args.poison:
@@ -548,6 +557,9 @@ def main():
                        "conv_tiles": ("table %s" % os.path.relpath(cache, ROOT)) if cache else
                                      ("autotuned in-sequence at setup" if args.autotune == "on" else "launcher heuristic"),
                        "backbone_pipeline": bool(args.stage == 1 and mode == "program" and args.pipeline == "on"),
+                       "step_overlap": ("the side lane's tail of step t (last optimizer sweeps + re-pack, last weight gradients) runs into "
+                                        "the locked-backbone forward of step t+1, per-tensor dependencies; bit-identical to the joined step")
+                                       if overlap else False,
                        "backbone_pair": ("locked conv1-52 run once per two batches at 2B; every batch passes every layer once; "
                                          "steps alternate (backbone + trainable part | trainable part), ms_per_step is their mean")
                                         if args.pair else False,

@@ -14,8 +14,11 @@ struct Cmd {
   hipEvent_t ev;
 };
 constexpr int NLANES = 3;   // lane 0 = the caller's stream, lanes 1.. = side streams owned by the list
+constexpr int NSLOTS = 16;  // named cross-replay marks (cmdlist_mark_slot / cmdlist_wait_slot)
 struct CmdList {
   std::vector<Cmd> cmds;
+  hipEvent_t slot_ev[NSLOTS] = {};
+  bool slot_recorded[NSLOTS] = {};
   hipStream_t side[NLANES] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[NLANES] = {nullptr, nullptr, nullptr};
   bool uses[NLANES] = {true, false, false};
@@ -109,6 +112,8 @@ extern "C" void disyolo_cmdlist_destroy(void* l) {
   for (Cmd& k : c->cmds)
     if (k.ev) (void)hipEventDestroy(k.ev);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  for (int i = 0; i < NSLOTS; ++i)
+    if (c->slot_ev[i]) (void)hipEventDestroy(c->slot_ev[i]);
   for (int i = 1; i < NLANES; ++i) {
     if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
@@ -164,6 +169,29 @@ extern "C" int disyolo_cmdlist_wait(int mark, int lane) {
   g_rec->uses[lane] = true;
   return DISYOLO_OK;
 }
+// Named marks that outlive a replay.  mark_slot: remember this point of `lane` under `slot`; wait_slot: `lane` waits for
+// the point the slot was LAST marked at -- by a mark earlier in this replay or, where the wait comes first in the list,
+// by the PREVIOUS replay of the list (nothing to wait for on the first one).  This is how a step's tail on the side
+// lane (optimizer sweeps, the last weight gradients) overlaps the next step's locked-backbone forward on the main
+// lane: the next replay waits, tensor by tensor, only for the side-lane work that still reads or writes it.
+extern "C" int disyolo_cmdlist_mark_slot(int lane, int slot) {
+  DY_REQUIRE(lane >= 0 && lane < NLANES && slot >= 0 && slot < NSLOTS, "cmdlist_mark_slot: lane 0..%d, slot 0..%d", NLANES - 1, NSLOTS - 1);
+  if (!g_rec) return DISYOLO_OK;
+  if (!g_rec->slot_ev[slot] && hipEventCreateWithFlags(&g_rec->slot_ev[slot], hipEventDisableTiming) != hipSuccess) {
+    disyolo_set_error("cmdlist_mark_slot: hipEventCreate failed");
+    return DISYOLO_E_HIP;
+  }
+  g_rec->cmds.push_back(Cmd{nullptr, 4, 0, lane, slot, nullptr});
+  g_rec->uses[lane] = true;
+  return DISYOLO_OK;
+}
+extern "C" int disyolo_cmdlist_wait_slot(int slot, int lane) {
+  DY_REQUIRE(lane >= 0 && lane < NLANES && slot >= 0 && slot < NSLOTS, "cmdlist_wait_slot: lane 0..%d, slot 0..%d", NLANES - 1, NSLOTS - 1);
+  if (!g_rec) return DISYOLO_OK;
+  g_rec->cmds.push_back(Cmd{nullptr, 5, 0, slot, lane, nullptr});
+  g_rec->uses[lane] = true;
+  return DISYOLO_OK;
+}
 extern "C" int disyolo_cmdlist_end(void) {
   DY_REQUIRE(g_rec, "cmdlist_end: not recording");
   g_rec = nullptr;
@@ -216,6 +244,17 @@ extern "C" int disyolo_cmdlist_run_ex(void* l, int first, int last, void* stream
     } else if (k.kind == 2) {
       if (hipEventRecord(k.ev, lanes[k.from]) != hipSuccess) {
         disyolo_set_error("cmdlist_run: mark failed");
+        return DISYOLO_E_HIP;
+      }
+    } else if (k.kind == 4) {
+      if (hipEventRecord(c->slot_ev[k.to], lanes[k.from]) != hipSuccess) {
+        disyolo_set_error("cmdlist_run: slot mark failed");
+        return DISYOLO_E_HIP;
+      }
+      c->slot_recorded[k.to] = true;
+    } else if (k.kind == 5) {
+      if (c->slot_recorded[k.from] && hipStreamWaitEvent(lanes[k.to], c->slot_ev[k.from], 0) != hipSuccess) {
+        disyolo_set_error("cmdlist_run: slot wait failed");
         return DISYOLO_E_HIP;
       }
     } else if (k.kind == 3) {

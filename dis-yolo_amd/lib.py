@@ -144,6 +144,8 @@ _SIGS = {
     "disyolo_cmdlist_sync": (C.c_int, [C.c_int, C.c_int]),
     "disyolo_cmdlist_mark": (C.c_int, [C.c_int]),
     "disyolo_cmdlist_wait": (C.c_int, [C.c_int, C.c_int]),
+    "disyolo_cmdlist_mark_slot": (C.c_int, [C.c_int, C.c_int]),
+    "disyolo_cmdlist_wait_slot": (C.c_int, [C.c_int, C.c_int]),
     "disyolo_cmdlist_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "disyolo_cmdlist_run_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "disyolo_cmdlist_side_stream": (C.c_void_p, [C.c_void_p]),
@@ -931,6 +933,16 @@ def lane_mark(lane: int) -> int:
 def lane_wait(mark: Optional[int], lane: int) -> None:
     if mark is not None and mark >= 0:
         _check(load().disyolo_cmdlist_wait(mark, lane), "cmdlist_wait")
+
+
+def lane_mark_slot(lane: int, slot: int) -> None:
+    """named mark that outlives a replay (see lane_wait_slot)"""
+    _check(load().disyolo_cmdlist_mark_slot(lane, slot), "cmdlist_mark_slot")
+
+
+def lane_wait_slot(slot: int, lane: int) -> None:
+    """`lane` waits for the point `slot` was last marked at: earlier in this replay or in the previous replay of the list"""
+    _check(load().disyolo_cmdlist_wait_slot(slot, lane), "cmdlist_wait_slot")
 
 
 def adam_step_dev(w, grad, m, v, n, n_decay, lr, b1, b2, eps, l2, step_counter, grad_scale=1.0) -> None:

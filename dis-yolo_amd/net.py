@@ -179,6 +179,12 @@ class YOLONet(object):
         self._graph = None      # hipGraph of the recorded step (single GPU)
         self.opt_chunks = None      # slices of the arena the optimizer sweeps one by one (_plan_opt_chunks)
         self._side_streams = {}  # id(recorded list) -> its side lane as a torch stream
+        # build_program(overlap_tail=True): the recorded step does not join its side lane at the end -- the optimizer's last
+        # sweeps and the last weight gradients keep running while the NEXT replay's locked-backbone forward starts; the
+        # next replay waits, tensor by tensor, for the side-lane work that still reads it (cmdlist slots)
+        self._overlap = False
+        self._overlap_rec = False      # while such a step is being recorded
+        self._tail_open = False        # a replay's side lane may still be running: join before anything but the next replay
         self._progs = None      # [parity] -> (list, marks, bwd_end) of the pipelined step
         # conv1 + conv2 as ONE launch wherever both run in inference mode (the locked backbone of stage 1, every inference
         # net): conv1's output -- 170 MB at B = 8, one consumer, unused by the active mask subnet (yolo/yolo3_net_pos.py:163)
@@ -311,9 +317,11 @@ class YOLONet(object):
     def state_dict(self) -> Dict[str, torch.Tensor]:
         """Variables under the reference's checkpoint names/shapes (weights, BN gamma/beta/
         moving stats, biases; no optimizer slots -- train_yolo3_mask.py:41-58)."""
+        self.sync_lanes()
         return {k: v.detach().clone() for k, v in self.params.items()}
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        self.sync_lanes()
         for k, v in sd.items():
             if k not in self.params:
                 if strict:
@@ -610,6 +618,7 @@ class YOLONet(object):
     def refresh_weights(self) -> None:
         """(Re)pack the bf16 MFMA operands from the f32 masters and fold the locked /
         inference batch-norm statistics into per-channel scale/shift."""
+        self.sync_lanes()
         for l in self.layers:
             if l.idx > 1:
                 L.pack_weights(l.w, l.wp, l.wdg, l.k, l.cin, l.cout, l.cout_pad)
@@ -639,6 +648,11 @@ class YOLONet(object):
                     L.set_lane(1)
                 elif l.idx in (60, 68, 76):
                     L.set_lane(0)
+            if self._overlap_rec:
+                if l.idx in self._xstep_slot and (l.idx not in plan or plan[l.idx] is not None):
+                    L.lane_wait_slot(self._xstep_slot[l.idx], 0)      # the previous replay's last reader of this layer's output
+                if l.idx == self._xstep_first_trainable:
+                    L.lane_wait_slot(self.SLOT_ALL, 0)                # the previous replay's optimizer + re-pack
             if l.idx in plan:
                 if plan[l.idx] is not None:
                     plan[l.idx]()
@@ -656,6 +670,32 @@ class YOLONet(object):
             l = self.by_idx[i]
             if self.training and not l.lock and l.kind != "lin":
                 L.bn_fold(l.gamma, l.beta, l.mm, l.mv, cfg.BN_EPSILON, l.scale, l.shift)
+
+    SLOT_ALL = 15
+
+    def _plan_overlap(self) -> None:
+        """cross-replay dependencies of the overlapped tail: backbone outputs that trainable layers consume (their weight
+        gradients read them on the side lane) -> slot; the first trainable layer"""
+        P = self._backbone_prefix()
+        self._xstep_first_trainable = P + 1
+        self._xstep_slot, self._xstep_reader = {}, {}
+        slot = 0
+        for l in self.layers:
+            if l.idx <= P:
+                continue
+            for src in (l.src, l.src_up, l.shortcut):
+                if src is not None and 1 <= src <= P:
+                    if src not in self._xstep_slot:
+                        self._xstep_slot[src] = slot
+                        slot += 1
+                    # the LAST reader in backward order marks the slot (side lane, FIFO: earlier readers are done by then)
+                    self._xstep_reader[src] = l.idx
+        if slot >= self.SLOT_ALL:
+            raise L.DisyoloError("overlap_tail: too many backbone outputs feed trainable layers")
+        order = [x.idx for x in self.backward_order() if not x.lock]
+        for src in self._xstep_slot:
+            readers = [x.idx for x in self.layers if x.idx > P and src in (x.src, x.src_up, x.shortcut)]
+            self._xstep_reader[src] = max(readers, key=order.index)
 
     def _forward_first_two(self) -> None:
         l1, l2 = self.by_idx[1], self.by_idx[2]
@@ -812,7 +852,19 @@ class YOLONet(object):
             setattr(self, n, v)
         self._build_descs()
 
+    def sync_lanes(self) -> None:
+        """overlap_tail: order the caller's stream after the side lane's open tail (the last replay's optimizer).  Cheap (one
+        stream-to-stream wait, no host synchronisation); a no-op otherwise.  Everything that reads or writes training
+        state outside a replay calls it first."""
+        if self._tail_open and self._prog is not None:
+            side = self._side_streams.get(id(self._prog))
+            if side is None:
+                side = self._side_streams[id(self._prog)] = self._prog.side_stream(self.device)
+            torch.cuda.current_stream().wait_stream(side)
+        self._tail_open = False
+
     def _set_inputs(self, images, clip_window, half: int = 0) -> None:
+        self.sync_lanes()
         images = torch.as_tensor(images)
         if tuple(images.shape) != (self.B, self.S, self.S, 3):
             raise ValueError("images must be [%d,%d,%d,3] NHWC (batch size and image size are baked into the plan, "
@@ -923,6 +975,7 @@ class YOLONet(object):
     def shuffle_rois(self, generator: Optional[torch.Generator] = None) -> None:
         """tf.random_shuffle of proposals / GT boxes (yolo/yolo3_net_pos.py:781-782), host-driven
         (torch RNG).  A recorded step built with ``auto_shuffle`` does this on the device."""
+        self.sync_lanes()
         B = self.B
         self.perm_det.copy_(torch.rand(B, cfg.MAX_DETECTION, device=self.device, generator=generator).argsort(dim=1))
         self.perm_gt.copy_(torch.rand(B, cfg.MAX_BOX_PER_IMAGE, device=self.device, generator=generator).argsort(dim=1))
@@ -933,6 +986,8 @@ class YOLONet(object):
         """forward (training mode) + detections + both losses and their gradients wrt the
         head logits / score maps (yolo/yolo3_net_pos.py:59-60)."""
         self._reg_fresh = False
+        if not self._overlap_rec:
+            self.sync_lanes()
         self._forward_layers(True, first_layer)
         heads = [self.by_idx[75], self.by_idx[67], self.by_idx[59]]
         side = self.use_side_lane
@@ -1137,6 +1192,10 @@ class YOLONet(object):
                     L.upsample2x_bwd(kw["tmp"], up.grad, B, l.H, l.W, up.cout, 0, up.cout, accumulate=up.grad_set)
                     up.grad_set = True
             weight_gradient()
+            if self._overlap_rec:
+                for src, reader in self._xstep_reader.items():
+                    if reader == l.idx:
+                        L.lane_mark_slot(1 if side else 0, self._xstep_slot[src])
             if overlap_opt and side:
                 # the optimizer sweep of an arena slice (+ the re-pack of its layers) as soon as the slice's
                 # weight gradients are final, on the side lane behind them -- not at the end of the critical
@@ -1151,7 +1210,8 @@ class YOLONet(object):
                     L.set_lane(0)
             if on_layer_done is not None:
                 on_layer_done(l)
-        L.lane_sync(1, 0)
+        if not self._overlap_rec:
+            L.lane_sync(1, 0)
 
     def _apply_tiles(self) -> None:
         """rebuild everything that depends on a tile choice: batch-norm partial-sum buffers
@@ -1216,6 +1276,7 @@ class YOLONet(object):
 
     @property
     def step_count(self) -> int:
+        self.sync_lanes()
         return int(self.step_dev.item())
 
     # ---- optimizer: Adam as sweeps over slices of the arena ------------------------------
@@ -1304,6 +1365,7 @@ class YOLONet(object):
         """conf + class + coord + mask + l2 term as a device scalar (tf.losses.get_total_loss,
         yolo/yolo3_net_pos.py:61).  Valid after compute_losses(); the l2 term is evaluated on
         the current weights (inside a recorded step: the pre-update weights, like TF)."""
+        self.sync_lanes()
         if self.n_decay and not self._reg_fresh:
             # called between compute_losses() and the optimizer: evaluate the l2 term now; after
             # optimizer_step() / a recorded step reg_loss already holds it (written by the Adam sweep)
@@ -1312,7 +1374,7 @@ class YOLONet(object):
 
     # ---- recorded step: one C call (or one hipGraph launch) per iteration -------------
     def build_program(self, det_thresh: float = cfg.OBJ_THRESHOLD, graph: bool = False,
-                      pipeline_backbone: bool = False) -> None:
+                      pipeline_backbone: bool = False, overlap_tail: bool = False) -> None:
         """Record forward + losses + backward + Adam + re-pack into a command list
         (csrc/runtime.hip).  With data parallelism the list is cut where a gradient bucket
         becomes final so the RCCL all-reduces are issued between segments.
@@ -1325,6 +1387,18 @@ class YOLONet(object):
         """
         if not self.training:
             raise L.DisyoloError("build_program on a YOLONet built with training=False")
+        # ``overlap_tail`` (single GPU, list executor): the step does not join its side lane at the end.  The side lane still
+        # owes the optimizer sweeps of the slices that became final last (three quarters of the stage-1 parameters sit in the
+        # layers the backward pass reaches last) and the last weight gradients -- 0.15 ms during which the main lane was idle;
+        # the next replay starts its locked-backbone forward right away and waits, per tensor, for the side-lane work that
+        # still reads it (the weight gradients of the layers fed by backbone outputs) and, in front of the first trainable
+        # layer, for the optimizer + re-pack.  Same kernels, same order per lane: results bit-identical.  train_step(want_loss=
+        # True), total_loss(), forward(), set_batch(), state_dict() ... join first (sync_lanes()).
+        if overlap_tail and (graph or pipeline_backbone or self.pair or self.dp is not None or not self.use_side_lane):
+            raise L.DisyoloError("overlap_tail needs the single-GPU two-lane list executor (no graph / pipeline / pair / dp)")
+        self._overlap = bool(overlap_tail)
+        if self._overlap:
+            self._plan_overlap()
         if self.pair:
             # two lists: the even step = the backbone on both batches + the trainable part on the first half, the odd
             # step = the trainable part on the second half; run_program alternates
@@ -1353,7 +1427,11 @@ class YOLONet(object):
             self.ws_aux.frozen = True
             self._prog, self._prog_marks, self._bwd_end = self._progs[0]
             return
-        prog, marks, self._bwd_end = self._record_step(det_thresh, None)
+        self._overlap_rec = self._overlap
+        try:
+            prog, marks, self._bwd_end = self._record_step(det_thresh, None)
+        finally:
+            self._overlap_rec = False
         self.ws.frozen = True
         self.ws_aux.frozen = True
         self._prog, self._prog_marks = prog, marks
@@ -1422,7 +1500,16 @@ class YOLONet(object):
                 self.backward(sweep=True)
             bwd_end = prog.size()
             self._rec = None
-            self.optimizer_step(1.0 / self.dp.world_size if self.dp is not None else 1.0)
+            if self._overlap_rec:
+                # what is left of the optimizer (the slices that became final last, gamma / beta, the finish) stays on the side
+                # lane behind the last weight gradients; it needs the main lane's last batch-norm gradients
+                L.lane_wait(L.lane_mark(0), 1)
+                L.set_lane(1)
+                self.optimizer_step(1.0)
+                L.lane_mark_slot(1, self.SLOT_ALL)
+                L.set_lane(0)
+            else:
+                self.optimizer_step(1.0 / self.dp.world_size if self.dp is not None else 1.0)
         return prog, marks, bwd_end
 
     def run_program(self) -> None:
@@ -1433,7 +1520,8 @@ class YOLONet(object):
             self._graph.replay()
             return
         if self.dp is None or os.environ.get("DISYOLO_DP_NOSEG") == "1":
-            self._prog.run()
+            self._prog.run(join=not self._overlap)
+            self._tail_open = self._overlap
             return
         self.dp.begin_step()
         # every recorded list owns its side lane: the bucket's all-reduce must be ordered after the
@@ -1483,7 +1571,7 @@ class YOLONet(object):
                 self.set_batch(batch)
         if self._prog is not None:
             self.run_program()
-            return self.total_loss() if want_loss else None
+            return self.total_loss() if want_loss else None      # (total_loss joins an open tail)
         if self.pair:
             if self.dp is not None:
                 raise L.DisyoloError("backbone_pair is a single-GPU option (no gradient exchange point in its step)")
@@ -1512,6 +1600,7 @@ class YOLONet(object):
 
     def summaries(self) -> Dict[str, float]:
         """the 7 tf.summary scalars (yolo/yolo3_net_pos.py:62,743-747,860)."""
+        self.sync_lanes()
         v = self.losses.cpu().numpy()
         ml = float(self.mask_loss.cpu()[0])
         return {"object_loss": float(v[0]), "noobject_loss": float(v[1]), "class_loss": float(v[2]),

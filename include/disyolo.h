@@ -479,6 +479,11 @@ int disyolo_cmdlist_sync(int from_lane, int to_lane);
  * wait(mark, lane) makes `lane` wait for that point only -- not for what the marked lane recorded later */
 int disyolo_cmdlist_mark(int lane);
 int disyolo_cmdlist_wait(int mark, int lane);
+/* named marks that outlive a replay: wait_slot waits for the point the slot was LAST marked at -- earlier in this replay
+ * or in the previous replay of the list (no wait on the first).  Lets a step's side-lane tail overlap the next step's
+ * main-lane start with per-tensor dependencies (YOLONet.build_program(overlap_tail=True)).  slot 0..15. */
+int disyolo_cmdlist_mark_slot(int lane, int slot);
+int disyolo_cmdlist_wait_slot(int slot, int lane);
 int disyolo_cmdlist_run(void* list, int first, int last, void* stream);
 /* same with explicit fork/join control (flags bit 0 = fork at the start, bit 1 = join at the
  * end) for a step replayed in several ranges, and the side lane's hipStream_t so a caller can

@@ -523,6 +523,47 @@ def test_training_net_evaluated_between_steps_matches_an_inference_net(dev, stag
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("stage", [1, 2])
+def test_overlapped_tail_is_bit_identical_to_the_joined_step(dev, stage):
+    """build_program(overlap_tail=True): a replay does not join its side lane -- the optimizer's last sweeps and the last
+    weight gradients run into the next replay's locked-backbone forward, which waits per tensor (cross-replay slots of
+    the command list).  Same kernels in the same per-lane order: after 6 steps on changing batches every variable, Adam
+    moment and loss equals the joined program's bit for bit; inference between steps and state_dict() join by
+    themselves."""
+    B, S = 2, 64
+    batches = [O.synthetic_batch(B, S, seed=300 + t) for t in range(6)]
+    nets = []
+    for ov in (False, True):
+        net = YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=stage, seed=15)
+        net.set_batch(batches[0])
+        net.build_program(det_thresh=0.1, overlap_tail=ov)
+        nets.append(net)
+    plain, over = nets
+    assert over._overlap and (stage == 2 or sorted(over._xstep_slot) == [4, 9, 26, 43, 52])
+    lp, lo = [], []
+    for t in range(6):
+        lp.append(float(plain.train_step(batches[t], det_thresh=0.1).cpu()))
+        if t % 2 == 0:
+            lo.append(float(over.train_step(batches[t], det_thresh=0.1).cpu()))
+        else:
+            over.train_step(batches[t], det_thresh=0.1, want_loss=False)      # (the tail stays open into the next call)
+            assert over._tail_open
+            lo.append(float(over.total_loss().cpu()))
+    # (a batch whose positive RoI rounds to zero area gives a NaN mask loss -- the reference's own hazard, SURVEY.md B14)
+    assert np.isfinite(lp).sum() >= 4 and np.array_equal(np.asarray(lp), np.asarray(lo), equal_nan=True)
+    val = O.synthetic_batch(B, S, seed=399)
+    over.train_step(batches[0], det_thresh=0.1, want_loss=False)
+    plain.train_step(batches[0], det_thresh=0.1, want_loss=False)
+    pa = over.forward(val["images"], val["clip_window"], [0.1], is_training=False)
+    pb = plain.forward(val["images"], val["clip_window"], [0.1], is_training=False)
+    torch.cuda.synchronize()
+    for a, b in zip(list(pa[0]) + [pa[1], pa[2]], list(pb[0]) + [pb[1], pb[2]]):
+        assert torch.equal(a, b)
+    sa, sb = over.state_dict(), plain.state_dict()
+    assert all(torch.equal(sa[k], sb[k]) for k in sb)
+    assert torch.equal(over.adam_m, plain.adam_m) and torch.equal(over.adam_v, plain.adam_v)
+
+
 def test_device_shuffle_produces_fresh_uniform_permutations(dev):
     B = 64
     pd = torch.zeros(B, 30, dtype=torch.int32, device=dev)
