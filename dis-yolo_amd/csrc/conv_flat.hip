@@ -353,8 +353,6 @@ __global__ __launch_bounds__(MW* NWV* KG * 64) void conv_flat_kernel(ConvParams 
     for (int m = 0; m < MI; ++m)
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int f = m * NI + j;
         if (f % KG != kg) {
 #pragma unroll

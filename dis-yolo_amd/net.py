@@ -499,6 +499,7 @@ class YOLONet(object):
         afterwards (the step can be recorded).  Returns {layer: activation scale}."""
         if self.dtype != "fp8":
             raise L.DisyoloError("calibrate_fp8 on a bf16 net")
+        self.sync_lanes()
         self.fp8_ready = False
         for l in self._fp8_layers():
             self._forward_layer(l, False)
@@ -1355,6 +1356,7 @@ class YOLONet(object):
 
     def repack(self) -> None:
         """bf16 MFMA operands of every trainable layer from the f32 masters"""
+        self.sync_lanes()
         if self.opt_chunks is None:
             self._plan_opt_chunks()
         for ch in self.opt_chunks:
