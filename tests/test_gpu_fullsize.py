@@ -123,6 +123,10 @@ def test_conv_kernel_families_agree_at_full_size(dev, H, Cin, Cout):
     groups, the halo-reuse patch kernel -- with integer-valued operands whose products and sums
     are exact in f32: all summation orders must give the bit-identical f32 result, and the bf16
     epilogue (scale/shift, leaky, residual) the bit-identical bf16 result."""
+    yb_probe = torch.empty(B, H, H, Cout, dtype=torch.bfloat16, device=dev)
+    for tile in (19, 24, 25):     # the new families really run at these shapes (no silent fallback)
+        assert L.conv2d_tile(L.make_conv_desc(yb_probe[..., :Cin].contiguous() if Cin <= Cout else torch.empty(B, H, H, Cin, dtype=torch.bfloat16, device=dev),
+                                              torch.empty(Cout, 9 * Cin, dtype=torch.bfloat16, device=dev), yb_probe, 3, 1, tile=tile))[0] == tile
     g = torch.Generator(device=dev).manual_seed(H)
     x = torch.randint(-3, 4, (B, H, H, Cin), device=dev, generator=g).to(torch.bfloat16)
     w = torch.randint(-2, 3, (Cout, 9 * Cin), device=dev, generator=g).to(torch.bfloat16)
@@ -130,7 +134,9 @@ def test_conv_kernel_families_agree_at_full_size(dev, H, Cin, Cout):
     scale = torch.full((Cout,), 2.0 ** -9, device=dev)
     shift = torch.full((Cout,), 0.25, device=dev)
     outs_f32, outs_bf16 = [], []
-    for tile in (3, 6, 10, 12, 0x20d, 14, 16, 17, 18):
+    # (19 = patch kernel with 16 channels per block; 24 / 25 = flat-frame kernels on 32x32x16 MFMA: bf16 output only, their f32
+    #  launch falls back to the heuristic tile)
+    for tile in (3, 6, 10, 12, 0x20d, 14, 16, 17, 18, 19, 24, 25):
         y = torch.empty(B, H, H, Cout, dtype=torch.float32, device=dev)
         L.conv2d_fwd(L.make_conv_desc(x, w, y, 3, 1, out_f32=True, tile=tile))
         yb = torch.empty(B, H, H, Cout, dtype=torch.bfloat16, device=dev)
