@@ -346,11 +346,17 @@ class ConvTuner:
         self.current = 0              # tile code of the running pass (0 = launcher heuristic)
         self.events = {}              # (key, cand) -> [(start, end)]
         self.stats_rows = {}          # stats buffer address -> partial-sum rows the last launch into it wrote
+        self.covers = {}              # (key, cand) -> does the candidate's kernel cover the shape (else the launcher falls back)
 
     def launch(self, d: ConvDesc) -> None:
         key = conv_shape_key(d)
         keep = d.tile
         d.tile = self.current
+        ck = (key, self.current)
+        if ck not in self.covers:
+            # a tile that does not cover the shape resolves to the heuristic's pick: timing it would enter the heuristic into
+            # the table under a foreign id whenever it wins by noise
+            self.covers[ck] = (not self.current) or conv2d_tile(d)[0] == (self.current & 0xff)
         if d.stats:
             # the number of batch-norm partial-sum rows depends on the tile: the finalize that follows must sum
             # exactly the rows THIS candidate writes, or the tuning passes run on garbage statistics
@@ -362,7 +368,8 @@ class ConvTuner:
         e.record()
         d.tile = keep
         _check(rc, "conv2d_fwd")
-        self.events.setdefault((key, self.current), []).append((s, e))
+        if self.covers[ck]:
+            self.events.setdefault(ck, []).append((s, e))
 
     def table(self):
         """{key: {cand: median ms}}"""
