@@ -232,6 +232,7 @@ class CmdList:
     def __init__(self):
         self.h = load().disyolo_cmdlist_create()
         self.keep = []           # tensors / descriptors referenced by the recorded commands
+        self._side = None        # side_stream()'s torch wrapper
 
     def __del__(self):
         try:
@@ -264,8 +265,11 @@ class CmdList:
                "cmdlist_run")
 
     def side_stream(self, device) -> "torch.cuda.Stream":
-        """the side lane as a torch stream (to order an RCCL collective after it)"""
-        return torch.cuda.ExternalStream(load().disyolo_cmdlist_side_stream(self.h), device=device)
+        """the side lane as a torch stream (to order an RCCL collective, or the caller's stream, after it).  The wrapper
+        lives and dies with this list: the HIP stream is destroyed with it"""
+        if self._side is None:
+            self._side = torch.cuda.ExternalStream(load().disyolo_cmdlist_side_stream(self.h), device=device)
+        return self._side
 
 
 def same_pads(size: int, k: int, s: int):

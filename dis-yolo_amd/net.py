@@ -178,7 +178,6 @@ class YOLONet(object):
         self._prog_marks = []   # [(command index, layer)] all-reduce trigger points
         self._graph = None      # hipGraph of the recorded step (single GPU)
         self.opt_chunks = None      # slices of the arena the optimizer sweeps one by one (_plan_opt_chunks)
-        self._side_streams = {}  # id(recorded list) -> its side lane as a torch stream
         # build_program(overlap_tail=True): the recorded step does not join its side lane at the end -- the optimizer's last
         # sweeps and the last weight gradients keep running while the NEXT replay's locked-backbone forward starts; the
         # next replay waits, tensor by tensor, for the side-lane work that still reads it (cmdlist slots)
@@ -858,9 +857,7 @@ class YOLONet(object):
         stream-to-stream wait, no host synchronisation); a no-op otherwise.  Everything that reads or writes training
         state outside a replay calls it first."""
         if self._tail_open and self._prog is not None:
-            side = self._side_streams.get(id(self._prog))
-            if side is None:
-                side = self._side_streams[id(self._prog)] = self._prog.side_stream(self.device)
+            side = self._prog.side_stream(self.device)
             torch.cuda.current_stream().wait_stream(side)
         self._tail_open = False
 
@@ -1531,9 +1528,7 @@ class YOLONet(object):
         cuda = self.device.type == "cuda"          # (a plan-only net on the CPU drives the same cut loop in tests/test_dp_gloo.py)
         side = None
         if cuda:
-            side = self._side_streams.get(id(self._prog))
-            if side is None:
-                side = self._side_streams[id(self._prog)] = self._prog.side_stream(self.device)
+            side = self._prog.side_stream(self.device)
 
         def on_lane(use_side: bool):
             if not cuda:
