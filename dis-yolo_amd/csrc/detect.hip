@@ -85,18 +85,29 @@ __device__ __forceinline__ float nms_iou(const float4& a, const float4& b) {
 // Detection filter.  Stage 1: one block per (image, class): ordered compaction of the
 // candidates with score > thr and arg-max class == c, then greedy NMS (IoU > nms_thr
 // suppresses, at most max_det kept) as a repeated block-wide arg-max over the live list --
-// exact for any number of candidates, never a truncated sort.  Scores/boxes of the live
-// list sit in LDS when they fit (<= NMS_CAP), else in the global workspace.  Stage 2: one
-// block per image merges the per-class survivors: top max_det by score (ties: lower
-// candidate index), zero padded.
-constexpr int NMS_T = 256;
-constexpr int NMS_CAP = 3072;
+// exact for any number of candidates, never a truncated sort.  Stage 2: one block per image
+// merges the per-class survivors: top max_det by score (ties: lower candidate index), zero
+// padded.
+//
+// The live list sits in REGISTERS while it fits (<= NMS_K candidates per thread, 8,192 per
+// block: score and box of list position q are held by thread q % NMS_T).  One
+// round of the greedy loop is then ONE pass over a thread's slots -- suppress against the
+// last winner and find the thread's best survivor in the same sweep -- and ONE barrier: the
+// wave winners (score, position, box) go to LDS, double-buffered by round parity, and
+// every thread picks the block winner from the 16 entries.  An untrained network passes
+// thousands of candidates per class (random logits at 576^2: ~6,800 of 20,412); with the list
+// in global memory a round cost 16 us (two dependent sweeps + two barriers), 30 rounds = 0.5 ms
+// on the chain that holds up the mask subnet's backward pass; in registers a round is ~1 us.
+// Longer lists (one class taking > 8,192 candidates) keep the global-memory form.
+constexpr int NMS_T = 1024;
+constexpr int NMS_K = 8;
+constexpr int NMS_W = NMS_T / 64;
 constexpr int MAX_KEEP = 512;  // >= num_class * max_det
 
-template <bool IN_LDS>
-__device__ __forceinline__ int greedy_nms(int n, const int* list, const float4* boxes, float* live, float4* lbox,
-                                          float nms_thr, int max_det, int* kept_idx, float* kept_sc, float* s_ws,
-                                          int* s_wp) {
+__device__ __forceinline__ bool nms_better(float v2, int p2, float v, int p) { return v2 > v || (v2 == v && p2 < p); }
+
+__device__ __forceinline__ int greedy_nms_global(int n, const int* list, const float4* boxes, float* live, float nms_thr,
+                                                 int max_det, int* kept_idx, float* kept_sc, float* s_ws, int* s_wp) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int nk = 0;
   for (int it = 0; it < max_det; ++it) {
@@ -113,7 +124,7 @@ __device__ __forceinline__ int greedy_nms(int n, const int* list, const float4* 
     for (int o = 32; o > 0; o >>= 1) {
       const float v2 = __shfl_xor(bs, o, 64);
       const int p2 = __shfl_xor(bp, o, 64);
-      if (v2 > bs || (v2 == bs && p2 < bp)) {
+      if (nms_better(v2, p2, bs, bp)) {
         bs = v2;
         bp = p2;
       }
@@ -126,16 +137,16 @@ __device__ __forceinline__ int greedy_nms(int n, const int* list, const float4* 
     float wsc = s_ws[0];
     int wq = s_wp[0];
 #pragma unroll
-    for (int w = 1; w < NMS_T / 64; ++w) {
+    for (int w = 1; w < NMS_W; ++w) {
       const float v2 = s_ws[w];
       const int p2 = s_wp[w];
-      if (v2 > wsc || (v2 == wsc && p2 < wq)) {
+      if (nms_better(v2, p2, wsc, wq)) {
         wsc = v2;
         wq = p2;
       }
     }
     if (!(wsc > 0.f)) break;  // nothing alive (live scores are > thr >= 0); uniform exit
-    const float4 wb = IN_LDS ? lbox[wq] : boxes[list[wq]];
+    const float4 wb = boxes[list[wq]];
     if (tid == 0) {
       kept_idx[nk] = list[wq];
       kept_sc[nk] = wsc;
@@ -143,7 +154,7 @@ __device__ __forceinline__ int greedy_nms(int n, const int* list, const float4* 
     ++nk;
     for (int q = tid; q < n; q += NMS_T) {
       if (live[q] >= 0.f) {
-        const float4 bx = IN_LDS ? lbox[q] : boxes[list[q]];
+        const float4 bx = boxes[list[q]];
         if (q == wq || nms_iou(bx, wb) > nms_thr) live[q] = -1.f;
       }
     }
@@ -157,6 +168,7 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const float4* boxes, c
                                                           int* list_g, float* live_g, int* kept_idx, float* kept_sc,
                                                           int* kept_n) {
   const int b = blockIdx.x / C, c = blockIdx.x - b * C, tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
   boxes += (size_t)b * NC;
   scores += (size_t)b * NC;
   classes += (size_t)b * NC;
@@ -164,23 +176,23 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const float4* boxes, c
   float* live_glob = live_g + (size_t)blockIdx.x * NC;
   kept_idx += (size_t)blockIdx.x * max_det;
   kept_sc += (size_t)blockIdx.x * max_det;
-  __shared__ int s_wcnt[2][NMS_T / 64];
-  __shared__ float s_ws[NMS_T / 64];
-  __shared__ int s_wp[NMS_T / 64];
-  __shared__ float s_live[NMS_CAP];
-  __shared__ float4 s_box[NMS_CAP];
-  // ---- ordered compaction (wave ballots + one barrier per 256 candidates)
+  __shared__ int s_wcnt[2][NMS_W];
+  __shared__ float s_ws[2][NMS_W];
+  __shared__ int s_wp[2][NMS_W];
+  __shared__ float4 s_wb[2][NMS_W];
+  __shared__ int s_kidx[64];
+  __shared__ float s_ksc[64];
+  // ---- ordered compaction (wave ballots + one barrier per 1024 candidates)
   int total = 0;
   for (int base = 0, it = 0; base < NC; base += NMS_T, ++it) {
     const int i = base + tid;
     const bool f = (i < NC) && (scores[i] > thr) && (classes[i] == c);
     const unsigned long long mask = __ballot(f);
-    const int lane = tid & 63, wv = tid >> 6;
     if (lane == 0) s_wcnt[it & 1][wv] = __popcll(mask);
     __syncthreads();
     int off = total;
 #pragma unroll
-    for (int w = 0; w < NMS_T / 64; ++w) {
+    for (int w = 0; w < NMS_W; ++w) {
       const int cw = s_wcnt[it & 1][w];
       if (w < wv) off += cw;
       total += cw;
@@ -189,19 +201,98 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const float4* boxes, c
   }
   __syncthreads();  // list[] (global) written by this block, read below by all its threads
   const int n = total;
-  int nk;
-  if (n <= NMS_CAP) {
-    for (int q = tid; q < n; q += NMS_T) {
-      const int i = list[q];
-      s_live[q] = scores[i];
-      s_box[q] = boxes[i];
+  int nk = 0;
+  if (n <= NMS_K * NMS_T) {
+    float sc[NMS_K];
+    float4 bx[NMS_K];
+    float bs = -1.f;                 // this thread's best survivor: score, list position, box
+    int bp = 0x7fffffff;
+    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < NMS_K; ++k) {
+      const int q = tid + k * NMS_T;
+      sc[k] = -1.f;
+      bx[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < n) {
+        const int i = list[q];
+        sc[k] = scores[i];
+        bx[k] = boxes[i];
+      }
+      const bool take = sc[k] > bs;  // ascending positions: the lowest wins among equal scores
+      bs = take ? sc[k] : bs;
+      bp = take ? q : bp;
+      bb.x = take ? bx[k].x : bb.x;
+      bb.y = take ? bx[k].y : bb.y;
+      bb.z = take ? bx[k].z : bb.z;
+      bb.w = take ? bx[k].w : bb.w;
+    }
+    for (int it = 0; it < max_det; ++it) {
+      const int par = it & 1;
+      float ws = bs;
+      int wp = bp;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float v2 = __shfl_xor(ws, o, 64);
+        const int p2 = __shfl_xor(wp, o, 64);
+        if (nms_better(v2, p2, ws, wp)) {
+          ws = v2;
+          wp = p2;
+        }
+      }
+      if (wp == bp) {  // the wave winner's owner (a wave with nothing alive: every lane, the same values)
+        s_ws[par][wv] = ws;
+        s_wp[par][wv] = wp;
+        s_wb[par][wv] = bb;
+      }
+      __syncthreads();
+      float wsc = s_ws[par][0];
+      int wq = s_wp[par][0], ww = 0;
+#pragma unroll
+      for (int w = 1; w < NMS_W; ++w) {
+        const float v2 = s_ws[par][w];
+        const int p2 = s_wp[par][w];
+        if (nms_better(v2, p2, wsc, wq)) {
+          wsc = v2;
+          wq = p2;
+          ww = w;
+        }
+      }
+      if (!(wsc > 0.f)) break;  // nothing alive (live scores are > thr >= 0); uniform exit
+      const float4 wb = s_wb[par][ww];
+      if (tid == 0) {
+        s_kidx[nk] = wq;          // list position; the candidate index is looked up once, after the loop
+        s_ksc[nk] = wsc;
+      }
+      ++nk;
+      // suppress against the winner and find this thread's best survivor, one sweep.  Branch-free on purpose: the nested
+      // form "if (alive) { if (winner || iou > thr) kill; else if (better) take; }" came out of hipcc 7.2 never killing
+      // on the IoU test (caught by the many-candidates known-answer test)
+      bs = -1.f;
+      bp = 0x7fffffff;
+#pragma unroll
+      for (int k = 0; k < NMS_K; ++k) {
+        const int q = tid + k * NMS_T;
+        const float iou = nms_iou(bx[k], wb);
+        const bool kill = (q == wq) | (iou > nms_thr);
+        sc[k] = kill ? -1.f : sc[k];            // (dead slots stay at -1)
+        const bool take = sc[k] > bs;
+        bs = take ? sc[k] : bs;
+        bp = take ? q : bp;
+        bb.x = take ? bx[k].x : bb.x;
+        bb.y = take ? bx[k].y : bb.y;
+        bb.z = take ? bx[k].z : bb.z;
+        bb.w = take ? bx[k].w : bb.w;
+      }
     }
     __syncthreads();
-    nk = greedy_nms<true>(n, list, boxes, s_live, s_box, nms_thr, max_det, kept_idx, kept_sc, s_ws, s_wp);
+    if (tid < nk) {
+      kept_idx[tid] = list[s_kidx[tid]];
+      kept_sc[tid] = s_ksc[tid];
+    }
   } else {
     for (int q = tid; q < n; q += NMS_T) live_glob[q] = scores[list[q]];
     __syncthreads();
-    nk = greedy_nms<false>(n, list, boxes, live_glob, nullptr, nms_thr, max_det, kept_idx, kept_sc, s_ws, s_wp);
+    nk = greedy_nms_global(n, list, boxes, live_glob, nms_thr, max_det, kept_idx, kept_sc, s_ws[0], s_wp[0]);
   }
   if (tid == 0) kept_n[blockIdx.x] = nk;
 }

@@ -124,6 +124,77 @@ def test_detect_clips_to_the_window_before_nms_and_caps_at_max_detection(dev):
     assert want[1, :cnt[1], :4].min() >= 0.25 and want[1, :cnt[1], :4].max() <= 0.75
 
 
+@pytest.mark.parametrize("case", ["balanced", "one_class", "sparse", "ties"])
+def test_detect_greedy_nms_on_thousands_of_candidates(dev, case):
+    """The detection filter's greedy loop at the sizes an untrained network produces (576^2: 20,412 candidates per image,
+    thousands per class over the threshold) -- list in registers (<= 8,192 per class), list in global memory (one class
+    takes more), a handful of candidates, and blocks of exactly equal scores -- replayed by the oracle's
+    non_max_suppression + top-k merge on the boxes / scores / classes the decode kernel itself produced (read back from
+    the workspace), so the comparison is exact: any difference is a different NMS decision."""
+    S_, B = 576, 2
+    g = torch.Generator().manual_seed({"balanced": 1, "one_class": 2, "sparse": 3, "ties": 4}[case])
+    ys = [torch.randn(B, gs, gs, 3, 8, generator=g) for gs in (72, 36, 18)]
+    thr = 0.25
+    for y in ys:
+        y[..., 2:4] *= 0.5
+        if case == "one_class":
+            y[..., 4] += 3.0
+            y[..., 5] += 4.0                      # nearly every candidate is class 0 and passes: > 8,192 in one list
+        elif case == "sparse":
+            y[..., 4] -= 3.0
+        elif case == "ties":
+            y[..., 4] = torch.round(y[..., 4])               # few distinct scores: long runs of equal ones
+            y[..., 5:] = torch.round(y[..., 5:]) * 40.0
+        else:
+            y[..., 4] += 1.5
+    anchors = np.asarray(cfg.ANCHORS, np.float32).reshape(-1)
+    win = torch.tensor([[0.0, 0.0, 1.0, 1.0], [0.1, 0.05, 0.9, 0.95]], device=dev)
+    max_det = cfg.MAX_DETECTION
+    nms_f32 = float(np.float32(cfg.IOU_THRESHOLD))     # the kernel compares in f32
+    det = torch.full((B, max_det, 6), float("nan"), device=dev)
+    cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    logits = [y.reshape(B, y.shape[1], y.shape[2], 24).contiguous().to(dev) for y in ys]
+    ws = L.Workspace(dev)
+    L.detect(logits[0], logits[1], logits[2], B, S_, 3, anchors, win, thr, cfg.IOU_THRESHOLD, max_det, det, cnt, ws)
+    torch.cuda.synchronize()
+    NC = 3 * (72 * 72 + 36 * 36 + 18 * 18)
+    raw = ws.buf.cpu().numpy()
+    boxes = raw[:B * NC * 16].view(np.float32).reshape(B, NC, 4)
+    scores = raw[B * NC * 16:B * NC * 20].view(np.float32).reshape(B, NC)
+    classes = raw[B * NC * 20:B * NC * 24].view(np.int32).reshape(B, NC)
+    want = np.zeros((B, max_det, 6), np.float32)
+    biggest = 0
+    for b in range(B):
+        keep = np.where(scores[b] > np.float32(thr))[0]
+        kept = []
+        for c in np.unique(classes[b][keep]):
+            ixs = keep[classes[b][keep] == c]
+            biggest = max(biggest, len(ixs))
+            # (the oracle's loop, candidates pre-sorted with numpy: its pure-Python sort key is the slow part at this size)
+            order = np.lexsort((np.arange(len(ixs)), -scores[b][ixs].astype(np.float64)))
+            sel = []
+            for j in order:
+                if len(sel) >= max_det:
+                    break
+                if all(O._tf_iou(boxes[b][ixs[j]], boxes[b][ixs[q]]) <= nms_f32 for q in sel):
+                    sel.append(j)
+            kept.extend(int(ixs[q]) for q in sel)
+        kept = np.array(sorted(set(kept)), dtype=np.int64)
+        order = sorted(range(len(kept)), key=lambda q: (-float(scores[b][kept[q]]), q))[:max_det]
+        for r, q in enumerate(order):
+            want[b, r, :4] = boxes[b][kept[q]]
+            want[b, r, 4] = classes[b][kept[q]]
+            want[b, r, 5] = scores[b][kept[q]]
+        assert int(cnt[b]) == len(order)
+    if case == "one_class":
+        assert biggest > 8192
+    elif case in ("balanced", "ties"):
+        assert 1024 < biggest <= 8192
+    else:
+        assert 0 < biggest < 1024
+    np.testing.assert_array_equal(det.cpu().numpy(), want)
+
+
 # ---------------------------------------------------------------------------------------------
 SM = 32          # score-map size (S/2): k/32 is dyadic, so box*SM lands exactly on x.5
 
