@@ -329,6 +329,7 @@ struct Wg3Params {
   const bf16* dy;
   float* out;  // slabs [splits][9*Cin][Cout]
   int B, H, W, Cin, Cout, ldy;
+  int Ho, Wo;               // output map (= H, W at stride 1; H/2, W/2 at stride 2)
   int P, Hp, frame, kbias;  // P = W+1, Hp = H+1, frame = Hp*P, kbias*frame >= the prologue's reach below Q = 0
   int a64, r64;             // 64 = a64*P + r64
   int chunks, chunks_per_split;
@@ -367,6 +368,18 @@ __device__ __forceinline__ int pix_index(const PixState& s, const Wg3Params& p) 
   return ok ? (s.b * p.H + s.yy - 1) * p.W + s.xx - 1 : -1;
 }
 
+// stride 2 (pad 0 before, 1 after: even H, W): the frame is the OUTPUT map with the pad column / row at the END of a row /
+// image, P = Wo+1, Hp = Ho+1; a frame position is output pixel (yy, xx) and, in parity class (py, px) of the input,
+// input pixel (2yy+py, 2xx+px)
+__device__ __forceinline__ int pix_index_s2_in(const PixState& s, const Wg3Params& p) {     // class (0, 0)
+  const bool ok = ((unsigned)s.b < (unsigned)p.B) && (s.yy < p.Ho) && (s.xx < p.Wo);
+  return ok ? (s.b * p.H + 2 * s.yy) * p.W + 2 * s.xx : -1;
+}
+__device__ __forceinline__ int pix_index_s2_out(const PixState& s, const Wg3Params& p) {
+  const bool ok = ((unsigned)s.b < (unsigned)p.B) && (s.yy < p.Ho) && (s.xx < p.Wo);
+  return ok ? (s.b * p.Ho + s.yy) * p.Wo + s.xx : -1;
+}
+
 // LDS-DMA with an immediate byte offset added to the per-lane source offset (still range-checked).
 // The hardware adds the instruction offset to the LDS address as well (LDS address = M0 base +
 // instruction offset + 16 * lane), so it is taken off the base again.
@@ -381,7 +394,12 @@ __device__ __forceinline__ void dma16_imm(unsigned voff, i32x4 srd, unsigned lds
 // NW = 4: one wave per SIMD, every wave all nine taps.  NW = 8: two waves per SIMD -- waves 0-3 take taps 0-4,
 // waves 4-7 taps 5-8 of the same (input fragment, channel half): half the accumulators per wave, no reduction
 // between the groups, and two instruction streams per SIMD to interleave (the one-wave loop is issue-bound).
-template <int CO_T, int R, int ST, int NW>
+//
+// S2 = 1: the stride-2 layers (conv2 / 5 / 10 / 27 / 44).  Tap (kh, kw) reads input pixel (2yo+kh, 2xo+kw): ONE of the four
+// parity classes of the input, (kh&1, kw&1), at a uniform shift of (kh>>1) rows + (kw>>1) pixels in the output-map frame
+// -- so the input is staged as FOUR rings, one per class (every input pixel still crosses into LDS exactly once), and a tap
+// is a (ring, row shift) pair: taps (0,0) (0,2) (2,0) (2,2) read class 0, (0,1) (2,1) class 1, (1,0) (1,2) class 2, (1,1) class 3.
+template <int CO_T, int R, int ST, int NW, int S2 = 0>
 __global__ __launch_bounds__(NW * 64) void conv_wgrad3x3_kernel(Wg3Params p) {
   constexpr int NJ = CO_T / 32;      // 16-channel gradient fragments per wave (the wave owns CO_T/2 channels)
   constexpr int YD = CO_T / 32;      // 32-channel sub-tiles of a gradient stage
@@ -390,8 +408,11 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad3x3_kernel(Wg3Params p) {
   constexpr int YST = YD * 4096;     // bytes per gradient stage: YD sub-tiles of [64 pixels][32 channels]
   constexpr int XRING = R * 4096;
   constexpr int XALLOC = XRING + 1024;   // + a copy of the ring's first 16 rows behind its end (see below)
+  constexpr int NR = S2 ? 4 : 1;         // input rings
+  constexpr int XTOT = NR * XALLOC;
   constexpr int PRE = ST - 1;
-  constexpr int LPT0 = 1 + YDW, LPT1 = YDW;   // DMAs per chunk of the waves that stage the input / that do not
+  constexpr int LPT0 = NR + YDW, LPT1 = YDW;   // DMAs per chunk of the waves that stage the input / that do not
+  static_assert(!S2 || NW == 4, "stride 2: the four-wave form only");
   static_assert((R & (R - 1)) == 0 && ST >= 2, "ring");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -432,21 +453,31 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad3x3_kernel(Wg3Params p) {
   pix_init(ys, c0 * 64 + drow, p);
   const unsigned xrow_bytes = (unsigned)p.Cin * 2u, yrow_bytes = (unsigned)p.ldy * 2u;
   auto issue_x = [&](int c) {   // stages chunk c of the input (this wave's quarter), advances the lane's pixel
-    const int pix = pix_index(xs, p);
-    const unsigned voff = pix >= 0 ? (unsigned)pix * xrow_bytes + x_const : OOB;
     const unsigned slot = (unsigned)(c & (R - 1));
-    // rows 0..15 of the ring are also kept behind its end: a fragment's second transposed read is the
-    // first + 16 rows, which then never needs the wrap-around mask
-    if (tg == 0) {
-      if (wave == 0 && slot == 0) dma16(voff, srdx, lds0 + XRING);
-      dma16(voff, srdx, lds0 + slot * 4096u + wq * 1024u);
+    if constexpr (S2) {
+      const int pix = pix_index_s2_in(xs, p);
+#pragma unroll
+      for (int cls = 0; cls < 4; ++cls) {
+        const unsigned voff = pix >= 0 ? (unsigned)(pix + (cls >> 1) * p.W + (cls & 1)) * xrow_bytes + x_const : OOB;
+        if (wave == 0 && slot == 0) dma16(voff, srdx, lds0 + cls * XALLOC + XRING);
+        dma16(voff, srdx, lds0 + cls * XALLOC + slot * 4096u + wq * 1024u);
+      }
+    } else {
+      const int pix = pix_index(xs, p);
+      const unsigned voff = pix >= 0 ? (unsigned)pix * xrow_bytes + x_const : OOB;
+      // rows 0..15 of the ring are also kept behind its end: a fragment's second transposed read is the
+      // first + 16 rows, which then never needs the wrap-around mask
+      if (tg == 0) {
+        if (wave == 0 && slot == 0) dma16(voff, srdx, lds0 + XRING);
+        dma16(voff, srdx, lds0 + slot * 4096u + wq * 1024u);
+      }
     }
     pix_advance64(xs, p);
   };
   auto issue_y = [&](int stage) {
-    const int pix = pix_index(ys, p);
+    const int pix = S2 ? pix_index_s2_out(ys, p) : pix_index(ys, p);
     const unsigned voff = pix >= 0 ? (unsigned)pix * yrow_bytes + y_const : OOB;
-    const unsigned dst = lds0 + XALLOC + stage * YST + (NW == 8 ? tg * 4096u : 0u) + wq * 1024u;
+    const unsigned dst = lds0 + XTOT + stage * YST + (NW == 8 ? tg * 4096u : 0u) + wq * 1024u;
     dma16_imm<0>((y_n < p.ldy) ? voff : OOB, srdy, dst);
     if constexpr (NW == 4) {
       dma16_imm<64>((y_n + 32 < p.ldy) ? voff : OOB, srdy, dst + 4096u);
@@ -462,18 +493,20 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad3x3_kernel(Wg3Params p) {
 
   // ---- fragment read addresses
   const int g = lane >> 4, li = lane & 15, q = li >> 2, pc = li & 3;
-  int E[TPW];
+  int E[TPW], EC[TPW];      // byte address of the tap's fragment inside its ring at chunk 0; the ring
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
     const int tap = tap0 + i;
-    const int rowc = (tap / 3 - 1) * p.P + (tap % 3 - 1) + 4 * g + q;
+    const int kh = tap / 3, kw = tap % 3;
+    const int rowc = (S2 ? (kh >> 1) * p.P + (kw >> 1) : (kh - 1) * p.P + (kw - 1)) + 4 * g + q;
     E[i] = rowc * 64 + ((u ^ ((rowc >> 2) & 1)) * 32) + pc * 8;
+    EC[i] = S2 ? ((kh & 1) * 2 + (kw & 1)) * XALLOC : 0;
   }
   int Fy[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int f = ch * NJ + j, row = 4 * g + q;
-    Fy[j] = XALLOC + (f >> 1) * 4096 + row * 64 + (((f & 1) ^ ((row >> 2) & 1)) * 32) + pc * 8;
+    Fy[j] = XTOT + (f >> 1) * 4096 + row * 64 + (((f & 1) ^ ((row >> 2) & 1)) * 32) + pc * 8;
   }
 
   f32x4 acc[TPW][NJ];
@@ -521,7 +554,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad3x3_kernel(Wg3Params p) {
 #pragma unroll
       for (int i = 0; i < TPW; ++i) {
         if (NW == 8 && i >= ntaps) continue;       // (wave-uniform: the last slot of the second tap group is unused)
-        const char* a = smem + ((E[i] + T + ks * 2048) & (XRING - 1));
+        const char* a = smem + EC[i] + ((E[i] + T + ks * 2048) & (XRING - 1));
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 1024));
         const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -637,17 +670,25 @@ void plan(const disyolo_conv_desc* d, int* bn, int* splits, int* steps_per_split
 
 
 struct Plan3 {
-  int co_t, R, splits, cps, chunks, tilesCi, tilesCo, leadA, leadB, st;
+  int co_t, R, splits, cps, chunks, tilesCi, tilesCo, leadA, leadB, st, s2;
   size_t lds;
 };
-// tap-fused kernel: 3x3, stride 1, SAME pads, no fused concat, 32 | Cin, 4 | Cout
+// tap-fused kernel: 3x3, SAME pads, no fused concat, 32 | Cin, 4 | Cout; stride 1, or stride 2 on even maps (pad 0 before,
+// 1 after) where four rings of 8 chunks fit (output rows up to 319 pixels)
 bool plan3(const disyolo_conv_desc* d, int opts, Plan3* q) {
   static const int enabled = env_int("DISYOLO_WG3", 1);
+  static const int s2_enabled = env_int("DISYOLO_WG3_S2", 1);
   static const int target = env_int("DISYOLO_WG3_BLOCKS", 256);
   if (!enabled || (opts & DISYOLO_WGRAD_IM2COL)) return false;
-  if (d->ksize != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->C1 != 0 || d->in_div != 1) return false;
-  if (d->C0 % 32 || d->Cout % 4 || d->Cout < 32 || d->Ho != d->H || d->Wo != d->W) return false;
-  const int P = d->W + 1, Hp = d->H + 1;
+  if (d->ksize != 3 || d->C1 != 0 || d->in_div != 1 || d->C0 % 32 || d->Cout % 4 || d->Cout < 32) return false;
+  q->s2 = 0;
+  if (d->stride == 2) {
+    if (!s2_enabled || d->pad_t != 0 || d->pad_l != 0 || (d->H & 1) || (d->W & 1) || d->Ho * 2 != d->H || d->Wo * 2 != d->W) return false;
+    q->s2 = 1;
+  } else if (d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->Ho != d->H || d->Wo != d->W) {
+    return false;
+  }
+  const int P = d->Wo + 1, Hp = d->Ho + 1;
   static const int cot_env = env_int("DISYOLO_WG3_COT", 0);
   q->co_t = d->Cout > 64 ? 128 : 64;
   if (cot_env == 64) q->co_t = 64;
@@ -657,14 +698,15 @@ bool plan3(const disyolo_conv_desc* d, int opts, Plan3* q) {
     const int t128 = (d->C0 / 32) * ceil_div(d->Cout, 128);
     if ((target + t128 / 2) / t128 == 2) q->co_t = 64;
   }
-  q->leadB = ceil_div(P + 1, 64);
+  q->leadB = q->s2 ? 0 : ceil_div(P + 1, 64);
   q->leadA = 1 + P / 64;
+  if (q->s2) q->co_t = 64;                // (four rings: 132 KiB of input, 24 KiB of gradient stages)
   static const int st_env = env_int("DISYOLO_WG3_ST", 3);
   q->st = st_env < 3 ? 3 : (st_env > 5 ? 5 : st_env);     // pipeline stages of the gradient image (prefetch depth st - 1)
   for (;;) {
     const int need = (q->st - 1) + q->leadA + q->leadB + 1;
     q->R = need <= 8 ? 8 : (need <= 16 ? 16 : 32);
-    q->lds = (size_t)q->R * 4096 + 1024 + (size_t)q->st * 64 * (size_t)q->co_t * 2;
+    q->lds = (size_t)(q->s2 ? 4 : 1) * ((size_t)q->R * 4096 + 1024) + (size_t)q->st * 64 * (size_t)q->co_t * 2;
     if (need <= 32 && q->lds <= 160 * 1024) break;
     if (q->st > 3) { --q->st; continue; }
     if (q->co_t == 128) { q->co_t = 64; continue; }
@@ -700,6 +742,16 @@ int launch3w(const Wg3Params& p, const Plan3& q, hipStream_t s) {
   if (q.st == 5) return launch3s<CO_T, R, NW, 5>(p, q, s);
   if (q.st == 4) return launch3s<CO_T, R, NW, 4>(p, q, s);
   return launch3s<CO_T, R, NW, 3>(p, q, s);
+}
+int launch3_s2(const Wg3Params& p, const Plan3& q, hipStream_t s) {
+  static bool attr_done = false;
+  auto fn = conv_wgrad3x3_kernel<64, 8, 3, 4, 1>;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(fn, dim3(q.tilesCi * q.tilesCo * q.splits), dim3(256), q.lds, s, p);
+  return 0;
 }
 template <int CO_T, int R>
 int launch3(const Wg3Params& p, const Plan3& q, hipStream_t s) {
@@ -762,20 +814,23 @@ extern "C" int disyolo_conv2d_wgrad(const disyolo_conv_desc* d, const void* dy, 
     p.x = (const bf16*)d->x0;
     p.dy = (const bf16*)dy;
     p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->C0; p.Cout = d->Cout; p.ldy = dy_ld;
-    p.P = d->W + 1; p.Hp = d->H + 1; p.frame = p.Hp * p.P;
-    p.kbias = ceil_div((q3.leadB + 1) * 64, p.frame);
+    p.Ho = d->Ho; p.Wo = d->Wo;
+    p.P = d->Wo + 1; p.Hp = d->Ho + 1; p.frame = p.Hp * p.P;
+    p.kbias = q3.s2 ? 0 : ceil_div((q3.leadB + 1) * 64, p.frame);
     p.a64 = 64 / p.P; p.r64 = 64 % p.P;
     p.chunks = q3.chunks; p.chunks_per_split = q3.cps;
     p.tilesCi = q3.tilesCi; p.tilesCo = q3.tilesCo; p.tiles = q3.tilesCi * q3.tilesCo;
     p.leadA = q3.leadA; p.leadB = q3.leadB;
     p.bytesx = (unsigned)((size_t)d->B * d->H * d->W * d->C0 * 2);
-    p.bytesy = (unsigned)((size_t)d->B * d->H * d->W * dy_ld * 2);
+    p.bytesy = (unsigned)((size_t)d->B * d->Ho * d->Wo * dy_ld * 2);
     p.out = q3.splits == 1 ? dw : (float*)workspace;
     static const int dbg = env_int("DISYOLO_WG3_DEBUG", 0);
     p.debug = dbg;
     hipStream_t s = (hipStream_t)stream;
     if (opts & DISYOLO_WGRAD_REDUCE_ONLY) goto reduce3;
-    if (q3.co_t == 128) {
+    if (q3.s2) {
+      launch3_s2(p, q3, s);
+    } else if (q3.co_t == 128) {
       if (q3.R == 8) launch3<128, 8>(p, q3, s);
       else if (q3.R == 16) launch3<128, 16>(p, q3, s);
       else launch3<128, 32>(p, q3, s);
