@@ -647,6 +647,171 @@ __global__ __launch_bounds__(1024) void conv_first_wgrad_kernel(const float* img
   slabs[(size_t)blockIdx.x * nout + o] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// First layer (Cin = 3, Cout = 32) on the matrix cores, taps as the M axis: dw[27][32] = sum over pixels of
+// x(pixel + tap)[c] * dy(pixel)[n] is a [32 x P] x [P x 32] product with the PIXELS as the reduction axis -- 27 of the 32
+// rows real, against 27 of 72 (K = 9 taps x 8 padded channels, 128-row tiles) in the im2col form this replaces.
+// Unit of work: 128 pixels of one image row.  Its gradient tile [128][32] comes in by LDS-DMA exactly like a chunk of the
+// tap-fused kernel (two [64 pixels][32 channels] images, same swizzle, same transposed reads, same k permutation: lane
+// group g holds pixels 4g..4g+3 and 16+4g..16+4g+3 of a 32-pixel group).  The image rows y-1..y+1 are loaded as f32,
+// rounded to bf16 and written to LDS as 27 rows, one per (kh, kw, c): row (kh, kw, c)[j] = x(y+kh-1, x0+j+kw-1)[c] -- the
+// three kw copies make every A fragment two aligned 8-byte reads (row pitch 272 B: conflict-free).  Wave w multiplies
+// pixel group w of the unit: 4 MFMAs per 4 + 4 LDS reads.  Two LDS stages, the next unit's DMA and image loads in flight
+// under the current unit's MFMAs; a block sums its four waves and writes one [27][32] slab.
+constexpr int F1_ROWB = 272;
+constexpr int F1_IMGB = 27 * F1_ROWB + 80;     // 7424: the gradient tile behind it stays 1 KiB-aligned
+constexpr int F1_STB = F1_IMGB + 8192;
+
+__global__ __launch_bounds__(512) void conv_first_wgrad_mfma_kernel(const float* img, const bf16* dy, float* slabs, int B,
+                                                                   int H, int W, int units_x, int nunits, unsigned bytesy) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  // two independent 4-wave groups per block, each walking its own units through its own two stages (twice the bytes in
+  // flight per CU for the same number of slabs; the block's barriers serve both)
+  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+  const int tid = threadIdx.x & 255, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned gbase = (unsigned)grp * 2u * F1_STB;
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pc = li & 3;
+  const i32x4 srdy = make_srd(dy, bytesy);
+  // gradient DMA: row 16*wave + lane/4 of each 64-pixel image, 16-byte piece lane%4 (source-side swizzle)
+  const int drow = wave * 16 + (lane >> 2), dpc = lane & 3;
+  const unsigned y_const = (unsigned)((((dpc >> 1) ^ ((drow >> 2) & 1)) * 16 + (dpc & 1) * 8) * 2);
+  // image loads: element e = tid (+256) of the 390 floats [x0-1, x0+128] x 3 channels of a row
+  int e_x[2], e_c[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int e = tid + h * 256;
+    e_x[h] = e / 3;
+    e_c[h] = e - e_x[h] * 3;
+  }
+  float iv[3][2];
+  auto unit_of = [&](int u, int& b, int& y, int& x0) {
+    const int xb = u % units_x, r = u / units_x;
+    y = r % H;
+    b = r / H;
+    x0 = xb * 128;
+  };
+  auto issue_dy = [&](int stage, int b, int y, int x0) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int x = x0 + s2 * 64 + drow;
+      const unsigned voff = x < W ? (unsigned)((b * H + y) * W + x) * 64u + y_const : OOB;
+      dma16(voff, srdy, lds0 + gbase + stage * F1_STB + F1_IMGB + s2 * 4096 + wave * 1024);
+    }
+  };
+  auto load_img = [&](int b, int y, int x0) {
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int yy = y + kh - 1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int x = x0 - 1 + e_x[h];
+        const bool ok = (tid + h * 256 < 390) && ((unsigned)yy < (unsigned)H) && ((unsigned)x < (unsigned)W);
+        iv[kh][h] = ok ? img[((size_t)(b * H + yy) * W + x) * 3 + e_c[h]] : 0.f;
+      }
+    }
+  };
+  auto write_img = [&](int stage) {
+    char* base = smem + gbase + stage * F1_STB;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (tid + h * 256 >= 390) continue;
+        const bf16 v = (bf16)iv[kh][h];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int j = e_x[h] - kw;
+          if ((unsigned)j < 128u) *reinterpret_cast<bf16*>(base + ((kh * 3 + kw) * 3 + e_c[h]) * F1_ROWB + j * 2) = v;
+        }
+      }
+  };
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int a_off = li * F1_ROWB + (32 * wave + 4 * g) * 2;             // row li (fragment 0); fragment 1 = row 16 + li
+  const bool a1_ok = 16 + li < 27;
+  const int brow = 4 * g + q;
+  int Fy[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    Fy[j] = F1_IMGB + (wave >> 1) * 4096 + (wave & 1) * 2048 + brow * 64 + ((j ^ ((brow >> 2) & 1)) * 32) + pc * 8;
+
+  int u = blockIdx.x * 2 + grp;
+  const int ustep = gridDim.x * 2;
+  int stage = 0;
+  if (u < nunits) {
+    int b, y, x0;
+    unit_of(u, b, y, x0);
+    issue_dy(0, b, y, x0);
+    load_img(b, y, x0);
+    write_img(0);
+  }
+  wait_vmcnt<0>();
+  __syncthreads();
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  // (both groups run the same number of rounds: the barriers are the block's)
+  const int rounds = (nunits - (int)blockIdx.x * 2 + ustep - 1) / ustep;
+  for (int it = 0; it < rounds; ++it, u += ustep) {
+    const int un = u + ustep;
+    const bool more = un < nunits;
+    if (more) {
+      int b, y, x0;
+      unit_of(un, b, y, x0);
+      issue_dy(stage ^ 1, b, y, x0);
+      load_img(b, y, x0);
+    }
+    const char* sb = smem + gbase + stage * F1_STB;
+    if (u < nunits) {
+    bf16x8 af[2], bfr[2];
+    {
+      const uint2 lo = *reinterpret_cast<const uint2*>(sb + a_off), hi = *reinterpret_cast<const uint2*>(sb + a_off + 32);
+      const uint4 v = {lo.x, lo.y, hi.x, hi.y};
+      af[0] = __builtin_bit_cast(bf16x8, v);
+      uint4 w = {0u, 0u, 0u, 0u};
+      if (a1_ok) {
+        const uint2 lo1 = *reinterpret_cast<const uint2*>(sb + a_off + 16 * F1_ROWB);
+        const uint2 hi1 = *reinterpret_cast<const uint2*>(sb + a_off + 16 * F1_ROWB + 32);
+        w = uint4{lo1.x, lo1.y, hi1.x, hi1.y};
+      }
+      af[1] = __builtin_bit_cast(bf16x8, w);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const char* a = sb + Fy[j];
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 1024));
+      const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      bfr[j] = __builtin_bit_cast(bf16x8, v);
+    }
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f], bfr[j], acc[f][j], 0, 0, 0);
+    }
+    if (more) write_img(stage ^ 1);
+    wait_vmcnt<0>();
+    __syncthreads();
+    stage ^= 1;
+  }
+  // ---- the eight waves' [32][32] sums -> one slab [27][32] per block
+  float* red = reinterpret_cast<float*>(smem);             // [8][32][32]
+  __syncthreads();
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((grp * 4 + wave) * 32 + 16 * f + 4 * g + r) * 32 + 16 * j + li] = acc[f][j][r];
+  __syncthreads();
+  float* slab = slabs + (size_t)blockIdx.x * 27 * 32;
+  for (int o = threadIdx.x; o < 27 * 32; o += 512)
+    slab[o] = ((red[o] + red[1024 + o]) + (red[2048 + o] + red[3072 + o])) + ((red[4096 + o] + red[5120 + o]) + (red[6144 + o] + red[7168 + o]));
+}
+
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && v[0]) ? atoi(v) : dflt;
@@ -891,10 +1056,17 @@ reduce1:
   return DISYOLO_OK;
 }
 
+static int first_wgrad_blocks(int B, int H, int W) {
+  const int64_t pairs = ((int64_t)B * H * ceil_div(W, 128) + 1) / 2;     // a block walks two units at a time
+  return (int)(pairs < 512 ? pairs : 512);         // two resident blocks per CU
+}
+
 extern "C" size_t disyolo_conv_first_wgrad_workspace(int B, int H, int W, int Cout) {
   const int64_t M = (int64_t)B * H * W;
   const int blocks = ceil_div(M, 1024);
-  return (size_t)blocks * 27 * Cout * sizeof(float);
+  const size_t direct = (size_t)blocks * 27 * Cout * sizeof(float);
+  const size_t mfma = (size_t)first_wgrad_blocks(B, H, W) * 27 * 32 * sizeof(float);
+  return direct > mfma ? direct : mfma;
 }
 
 extern "C" int disyolo_conv_first_wgrad(const float* images, const void* dy, float* dw, int B, int H, int W, int Cout,
@@ -906,12 +1078,25 @@ extern "C" int disyolo_conv_first_wgrad(const float* images, const void* dy, flo
   }
   DY_RECORD_OR_RUN([=](void* s) { return disyolo_conv_first_wgrad(images, dy, dw, B, H, W, Cout, workspace, workspace_bytes, s); });
   const int64_t M = (int64_t)B * H * W;
-  const int blocks = ceil_div(M, 1024);
   hipStream_t s = (hipStream_t)stream;
+  const int64_t n = 27 * Cout;
+  static const int use_mfma = env_int("DISYOLO_FIRST_WGRAD_MFMA", 1);
+  if (Cout == 32 && use_mfma && M * 64 < (1LL << 31)) {
+    // the matrix-core form (the layer as the reference builds it: 32 filters, yolo/yolo3_net_pos.py:159)
+    const int units_x = ceil_div(W, 128);
+    const int nunits = B * H * units_x;
+    const int blocks = first_wgrad_blocks(B, H, W);
+    hipLaunchKernelGGL(conv_first_wgrad_mfma_kernel, dim3(blocks), dim3(512), 4 * F1_STB, s, images, (const bf16*)dy,
+                       (float*)workspace, B, H, W, units_x, nunits, (unsigned)(M * 64));
+    DY_CHECK_LAUNCH();
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(n, 64)), dim3(256), 0, s, (const float*)workspace, dw, n, blocks);
+    DY_CHECK_LAUNCH();
+    return DISYOLO_OK;
+  }
+  const int blocks = ceil_div(M, 1024);
   hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3(blocks), dim3(1024), 0, s, images, (const bf16*)dy,
                      (float*)workspace, B, H, W, Cout, 1024);
   DY_CHECK_LAUNCH();
-  const int64_t n = 27 * Cout;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(n, 64)), dim3(256), 0, s, (const float*)workspace, dw, n,
                      blocks);
   DY_CHECK_LAUNCH();

@@ -463,7 +463,8 @@ class YOLONet(object):
                 if l.dx is not None and l.kind != "lin":
                     need = max(need, L.load().disyolo_bn_act_bwd_workspace(B * l.Ho * l.Wo, l.cout))
             if not l1.lock:
-                need = max(need, L.conv2d_wgrad_workspace(self._wgrad1_desc))
+                need = max(need, L.conv2d_wgrad_workspace(self._wgrad1_desc),
+                           L.load().disyolo_conv_first_wgrad_workspace(B, S, S, l1.cout))
             self.ws.get(int(need))
             self.ws_aux.get(int(need))
         self.ws_det.get(int(max(L.load().disyolo_detect_workspace(B, S, self.num_class), 1 << 20)))
@@ -1168,11 +1169,15 @@ class YOLONet(object):
                 if l.kind == "lin":
                     L.colsum(l.dx, l.dbias, M, L.GRAD_LD, l.cout, self.ws_aux)   # bias gradient
                 if l.idx == 1:
-                    # first layer through the same MFMA kernel: bf16 image padded to 8 channels,
-                    # K = 9*8 rows of which 27 are real
-                    L.image_pad8(self.images, self._img8)
-                    L.conv2d_wgrad(self._wgrad1_desc, l.dx, l.cout, self._dw8, self.ws_aux)
-                    L.copy2d_f32(self._dw8, l.dw, 9, 3 * l.cout, 8 * l.cout, 3 * l.cout)
+                    if l.cout == 32 and os.environ.get("DISYOLO_FIRST_WGRAD_MFMA", "1") != "0":
+                        # the first layer's own kernel: taps as the M axis of the MFMA, the f32 image rounded to bf16 on
+                        # its way into LDS (csrc/conv_wgrad.hip, conv_first_wgrad_mfma_kernel)
+                        L.conv_first_wgrad(self.images, l.dx, l.dw, self.ws_aux)
+                    else:
+                        # through the im2col kernel: bf16 image padded to 8 channels, K = 9*8 rows of which 27 are real
+                        L.image_pad8(self.images, self._img8)
+                        L.conv2d_wgrad(self._wgrad1_desc, l.dx, l.cout, self._dw8, self.ws_aux)
+                        L.copy2d_f32(self._dw8, l.dw, 9, 3 * l.cout, 8 * l.cout, 3 * l.cout)
                 elif os.environ.get("DISYOLO_EXP_SKIP_WGRAD") not in ("1", "2"):     # (experiment: the step without its weight gradients)
                     L.conv2d_wgrad(l.wgrad_desc, dx, ld, l.dw, self.ws_aux)
                 if side:

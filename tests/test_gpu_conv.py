@@ -651,6 +651,24 @@ def test_conv_wgrad_matches_autograd(dev, B, H, W, Cin, Cout, k, s):
     check(dw, want, 1e-4, 2e-4 * float(want.abs().max()))
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 576, 576), (2, 64, 200), (3, 7, 5), (1, 130, 129), (2, 33, 128), (1, 1, 1)])
+def test_first_layer_wgrad_on_the_matrix_cores(dev, B, H, W):
+    """conv1's weight gradient (3 -> 32 filters): taps as the M axis of the MFMA, 128-pixel row units, image rounded to bf16
+    on the way into LDS -- against autograd on the same bf16-rounded image; ragged rows (W not a multiple of 128, one
+    pixel past a unit), maps smaller than a unit, the full-size map"""
+    g = torch.Generator().manual_seed(B * 7 + H + W)
+    img = torch.rand(B, H, W, 3, generator=g) * 2 - 1
+    w = torch.randn(3, 3, 3, 32, generator=g, dtype=torch.float64, requires_grad=True)
+    y = O.conv2d_same(bf16r(img), w, 1)
+    dy = bf16r(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    want = w.grad
+    dw = torch.full((3, 3, 3, 32), float("nan"), dtype=torch.float32, device=dev)
+    L.conv_first_wgrad(img.to(dev), dy.to(torch.bfloat16).to(dev), dw, L.Workspace(dev))
+    torch.cuda.synchronize()
+    check(dw, want, 1e-4, 2e-4 * float(want.abs().max()))
+
+
 def test_wgrad_fused_concat(dev):
     g = torch.Generator().manual_seed(9)
     skip = bf16r(torch.randn(2, 12, 12, 64, generator=g))
