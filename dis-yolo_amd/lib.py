@@ -649,7 +649,7 @@ def conv2d_wgrad(d: ConvDesc, dy, dy_ld: int, dw, ws: Workspace, opts: int = 0) 
         # the partial-sum kernel and the slab reduction as two timed launches (same work, same order)
         kind, tn, ring, splits = conv2d_wgrad_plan(d, opts)
         waves = 8 if os.environ.get("DISYOLO_WG3_WAVES") == "8" else 4
-        name = ("conv_wgrad3x3_kernel<%d,%d,3,%d>" % (tn, ring, waves)) if kind == 1 else ("conv_wgrad_kernel<%d,3>" % tn)
+        name = ("conv_wgrad3x3_kernel<%d,%d,3,%d,0>" % (tn, ring, waves)) if kind == 1 else ("conv_wgrad_kernel<%d,3>" % tn)
         if kind == 1 and d.stride == 2:
             name = "conv_wgrad3x3_kernel<64,8,3,4,1>"
         TIMER.run(name, conv_flops(d), lambda: call(opts | WGRAD_PARTIAL_ONLY))
