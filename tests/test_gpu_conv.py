@@ -625,7 +625,9 @@ WGRAD = [(2, 18, 18, 64, 128, 3, 1), (2, 12, 12, 128, 64, 1, 1), (1, 20, 20, 32,
          # the same kernel on the stride-2 layers (four parity-class rings): conv2's full-size map (289-pixel frame rows, all
          # eight ring slots in use), conv5 / conv10 shapes, H != W, a frame smaller than a chunk, Cout not a multiple of 16
          (1, 576, 576, 32, 64, 3, 2), (2, 144, 144, 64, 128, 3, 2), (2, 36, 36, 128, 256, 3, 2), (3, 36, 28, 96, 36, 3, 2),
-         (5, 4, 6, 32, 64, 3, 2), (1, 72, 200, 32, 32, 3, 2)]
+         (5, 4, 6, 32, 64, 3, 2), (1, 72, 200, 32, 32, 3, 2),
+         # an output row too long for four 8-chunk rings (351-pixel frame rows): the planner falls back to im2col
+         (1, 6, 700, 32, 32, 3, 2)]
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,s", WGRAD)
@@ -646,6 +648,8 @@ def test_conv_wgrad_matches_autograd(dev, B, H, W, Cin, Cout, k, s):
     d = L.make_conv_desc(x.to(torch.bfloat16).to(dev), dummy, yd, k, s)
     if k == 3 and s == 2 and Cin % 32 == 0 and Cout >= 32 and W // 2 + 1 <= 320:
         assert L.conv2d_wgrad_plan(d)[0] == 1          # the tap-fused kernel, not im2col
+    if k == 3 and s == 2 and W // 2 + 1 > 320:
+        assert L.conv2d_wgrad_plan(d)[0] == 0
     L.conv2d_wgrad(d, dyp, ld, dw, L.Workspace(dev))
     torch.cuda.synchronize()
     check(dw, want, 1e-4, 2e-4 * float(want.abs().max()))
