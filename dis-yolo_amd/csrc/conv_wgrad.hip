@@ -843,7 +843,11 @@ struct Plan3 {
 bool plan3(const disyolo_conv_desc* d, int opts, Plan3* q) {
   static const int enabled = env_int("DISYOLO_WG3", 1);
   static const int s2_enabled = env_int("DISYOLO_WG3_S2", 1);
-  static const int target = env_int("DISYOLO_WG3_BLOCKS", 256);
+  // blocks aimed at per launch.  192, not one per CU: in the step these kernels run on the side lane beside the main
+  // lane's data-gradient convs, and a grid that leaves a quarter of the CUs free costs the weight gradient less than it gives
+  // the critical chain (interleaved A/B, ms per step at 256 / 192 / 160: stage 1 4.181 / 4.162 / 4.162, stage 2 9.849 / 9.807 /
+  // 9.846, 832^2 4.312 / 4.297 / 4.286; 384 and 512: +4 %)
+  static const int target = env_int("DISYOLO_WG3_BLOCKS", 192);
   if (!enabled || (opts & DISYOLO_WGRAD_IM2COL)) return false;
   if (d->ksize != 3 || d->C1 != 0 || d->in_div != 1 || d->C0 % 32 || d->Cout % 4 || d->Cout < 32) return false;
   q->s2 = 0;
