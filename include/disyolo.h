@@ -213,9 +213,12 @@ int disyolo_pack_weights_fp8(const float* w_hwio, void* w_fp8, int ksize, int Ci
                              float scale, void* stream);
 
 /* which kernel the launcher picks for this descriptor: kind 0 = im2col kernel (tile_n = channel tile),
- * 1 = tap-fused 3x3 kernel (tile_n = channel tile, ring = input ring slots); splits = pixel splits
+ * 1 = tap-fused 3x3 kernel, stride 1 or 2 (tile_n = channel tile, ring = input ring slots); splits = pixel splits
  * (f32 slabs summed by slab_reduce when > 1).  opts: DISYOLO_WGRAD_* as passed to disyolo_conv2d_wgrad. */
 int disyolo_conv2d_wgrad_plan(const disyolo_conv_desc* d, int opts, int* kind, int* tile_n, int* ring, int* splits);
+/* weight gradient of the first layer (yolo/yolo3_net_pos.py:159: 3 -> 32 filters, 3x3, stride 1): images f32 [B,H,W,3], dy bf16
+ * [B,H,W,Cout], dw f32 [3][3][3][Cout].  Cout == 32 runs on the matrix cores with the 27 (tap, channel) pairs as the M axis (the image
+ * is rounded to bf16 on its way into LDS); other Cout (27 * Cout <= 1024) by direct f32 accumulation. */
 size_t disyolo_conv_first_wgrad_workspace(int B, int H, int W, int Cout);
 int disyolo_conv_first_wgrad(const float* images, const void* dy, float* dw, int B, int H, int W,
                              int Cout, void* workspace, size_t workspace_bytes, void* stream);
