@@ -574,7 +574,7 @@ def main():
             "parity": {"status": "partial: oracle unpinned against TF1.x (no TF, no reference vectors for the graph)",
                        "end_to_end_tolerance": "HIP inference vs f32 oracle on a trained net at 576^2 B=8/B=1 and 832^2 B=4: >= 90 % of "
                                                "the oracle's detections found with the same class at box IoU >= 0.75, >= 65 % at IoU >= 0.9; "
-                                               "matched pairs: |score diff| <= 0.12, mask IoU (> 0.5) >= 0.8 each / >= 0.93 mean -- "
+                                               "matched pairs: |score diff| <= 0.12 for all but at most one pair of a batch (<= 0.3), median <= 0.06; mask IoU (> 0.5) >= 0.8 each / >= 0.93 mean -- "
                                                "the bf16-emulating oracle itself agrees with the f32 one no better",
                        "evidence": "tests/test_gpu_e2e_parity.py, profiles/r04_e2e_parity.json"},
             "model_flops": {"train_gflop_per_image": round(train_gflop, 1),

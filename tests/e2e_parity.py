@@ -134,6 +134,8 @@ def _agreement(ref_box, ref_mask, got_box, got_mask, S: int, det_thresh: float, 
         "hip_unmatched": n_extra, "ref_missed": missed,
         "box_iou_min": float(rows[:, 0].min()) if len(rows) else None,
         "score_absdiff_max": float(rows[:, 1].max()) if len(rows) else None,
+        "score_absdiff_2nd": float(np.sort(rows[:, 1])[-2]) if len(rows) > 1 else (float(rows[:, 1].max()) if len(rows) else None),
+        "score_absdiff_median": float(np.median(rows[:, 1])) if len(rows) else None,
         "mask_iou_min": float(rows[:, 2].min()) if len(rows) else None,
         "mask_iou_mean": float(rows[:, 2].mean()) if len(rows) else None,
         "ref_score_min": float(scores.min()) if n_ref else None,
