@@ -42,7 +42,7 @@ MFMA_PEAK_TFLOPS = 2500.0      # bf16 dense, MI355X_MICROARCH.md "Peak BF16/FP16
 
 
 HBM_PEAK_TBS = 8.0             # spec; ~6.3 TB/s measured copy
-PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r05_pmc_traffic.json" if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_pmc_traffic.json")) else "r04_pmc_traffic.json"
 
 
 def box_fingerprint(dev, local_rank: int = 0):
@@ -97,6 +97,7 @@ def box_fingerprint(dev, local_rank: int = 0):
         fp["conv_tflops"] = round(2.0 * 8 * 36 * 36 * 512 * 2304 / (ms_conv * 1e-3) / 1e12, 1)
         fp["copy_512MB_GBps_read_plus_write"] = round(2 * (512 << 20) / (ms_copy * 1e-3) / 1e9, 1)
         del x, w, y, src, dst
+        torch.cuda.empty_cache()      # (the 1 GB of scratch goes back before the net allocates)
     except Exception as e:
         fp["micro_error"] = repr(e)[:120]
     return fp
@@ -378,7 +379,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the stage-2 / B=32 inference lines of 'secondary'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--no-box", action="store_true", help="skip the box fingerprint (rocm-smi + the 36^2 layer / 64 MB copy micro-benchmark)")
+    ap.add_argument("--no-box", action="store_true", help="skip the box fingerprint (rocm-smi + the 36^2 layer / 512 MB copy micro-benchmark)")
     ap.add_argument("--pipeline", default="auto", choices=("auto", "on", "off"),
                     help="cross-step software pipeline of the locked backbone (stage 1): each step computes the "
                          "backbone forward of the NEXT batch on a third lane while it runs heads/losses/backward/Adam "
@@ -496,10 +497,10 @@ def main():
     pipe = args.stage == 1 and mode == "program" and args.pipeline == "on"
     if args.pipeline == "on" and not pipe:
         raise SystemExit("--pipeline on needs --stage 1 and --mode program")
-    overlap = (args.overlap_tail != "off" and mode == "program" and not use_dp and not args.pair and not pipe
+    overlap = (args.overlap_tail != "off" and mode == "program" and (not use_dp or net.dp.inlist) and not args.pair and not pipe
                and os.environ.get("DISYOLO_SIDE_LANE", "1") != "0")
     if args.overlap_tail == "on" and not overlap:
-        raise SystemExit("--overlap-tail on needs one GPU, --mode program, no --pair / --pipeline")
+        raise SystemExit("--overlap-tail on needs --mode program, no --pair / --pipeline, and (data parallel) the exchange in the list")
     if mode != "eager":
         net.build_program(graph=(mode == "graph"), pipeline_backbone=pipe, overlap_tail=overlap)
         if pipe:
@@ -522,7 +523,9 @@ def main():
     dt = float(np.median(regions))
     loss = loss_trace[-1]
     dp_trace = None
-    if net.dp is not None:
+    if net.dp is not None and net.dp.inlist:
+        dp_trace = net.dp.describe()     # the collectives are commands of the step: there is no host-side wait to trace
+    elif net.dp is not None:
         # after the timed regions: a few steps with the exchange traced (events around every bucket's wait)
         net.dp.trace = []
         for _ in range(5):
@@ -553,7 +556,7 @@ def main():
                        "images_per_gpu": B, "global_batch": B * world, "image_size": S,
                        "stage": "1: conv1-52 locked (shipped reference source)" if args.stage == 1 else
                                 "2: all 82 layers trainable",
-                       "parallelism": "dp%d%s" % (world, "+syncbn" if (use_dp and args.sync_bn) else ""), "rccl_buckets": (len(net.dp.buckets) + 1) if net.dp else 0, "optimizer": "adam(tf-form) lr=1e-4", "step_driver": mode,
+                       "parallelism": "dp%d%s" % (world, "+syncbn" if (use_dp and args.sync_bn) else ""), "rccl_buckets": ((len(net.opt_chunks) if net.dp.inlist else len(net.dp.buckets)) + 1) if net.dp else 0, "optimizer": "adam(tf-form) lr=1e-4", "step_driver": mode,
                        "conv_tiles": ("table %s" % os.path.relpath(cache, ROOT)) if cache else
                                      ("autotuned in-sequence at setup" if args.autotune == "on" else "launcher heuristic"),
                        "backbone_pipeline": bool(args.stage == 1 and mode == "program" and args.pipeline == "on"),
@@ -572,11 +575,12 @@ def main():
                        "loss_fetched_in_timed_region": False,
                        "box": box},
             "parity": {"status": "partial: oracle unpinned against TF1.x (no TF, no reference vectors for the graph)",
-                       "end_to_end_tolerance": "HIP inference vs f32 oracle on a trained net at 576^2 B=8/B=1 and 832^2 B=4: >= 90 % of "
-                                               "the oracle's detections found with the same class at box IoU >= 0.75, >= 65 % at IoU >= 0.9; "
-                                               "matched pairs: |score diff| <= 0.12 for all but at most one pair of a batch (<= 0.3), median <= 0.06; mask IoU (> 0.5) >= 0.8 each / >= 0.93 mean -- "
-                                               "the bf16-emulating oracle itself agrees with the f32 one no better",
-                       "evidence": "tests/test_gpu_e2e_parity.py, profiles/r04_e2e_parity.json"},
+                       "end_to_end_tolerance": "HIP inference vs f32 oracle on nets trained with per-step input jitter (2 seeds x 2 lengths) at 576^2 B=8/B=1 and "
+                                               "832^2 B=4/B=1: >= 95 % of the oracle's detections found with the same class at box IoU >= 0.75, >= 90 % at "
+                                               "IoU >= 0.9; every matched pair |score diff| <= 0.12 unless the bf16-emulating oracle moves THAT detection too "
+                                               "(then <= 1.5 x its move + 0.03); at every detected cell the raw t_xy / t_wh / confidence / class logits within "
+                                               "1.5 x the bf16 oracle's own deviation + 0.15 / 0.05 / 0.25 / 0.2; mask IoU (> 0.5) >= 0.85 each / >= 0.95 mean",
+                       "evidence": "tests/test_gpu_e2e_parity.py, profiles/r05_e2e_parity.json (per-pair table)"},
             "model_flops": {"train_gflop_per_image": round(train_gflop, 1),
                             "achieved_tflops_per_gpu": round(train_gflop * value / world / 1e3, 1),
                             "frac_of_mfma_peak": round(train_gflop * value / world / 1e3 / MFMA_PEAK_TFLOPS, 4)},
@@ -619,9 +623,16 @@ def main():
                         PMC_TRAFFIC_FILE, pmc.get("measured_at", "?"))
             except Exception:
                 pass
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "timed_with": "HIP events, %d eager steps of the same workload" % args.steps, "achieved": round(achieved, 1),
+            ridge = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_TBS * 1e12)
+            alg_bytes = r.get("bytes_total", 0) / r["launches"]
+            intensity = (r["flops_total"] / r["bytes_total"]) if r.get("bytes_total", 0) > 0 else float("inf")
+            out["roofline"] = {"bound": "mfma" if intensity >= ridge else "hbm",
+                               "bound_from": "algorithmic FLOP per byte of this instance %.0f vs ridge %.0f (2.5 PF / 8 TB/s)" % (intensity, ridge),
+                               "kernel": dom, "timed_with": "HIP events, %d eager steps of the same workload" % args.steps, "achieved": round(achieved, 1),
                                "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                               "algorithmic_bytes": round(alg_bytes),
+                               "algorithmic_bytes_definition": "inputs + packed weights + output (+ residual), each once, averaged over this instance's launches",
                                "traffic_source": traffic_src,
                                "flops_per_launch": round(r["flops_total"] / r["launches"] / 1e9, 3),
                                "flops_per_launch_unit": "GFLOP (algorithmic, 2*M*N*K averaged over this kernel's launches)",
@@ -629,7 +640,6 @@ def main():
                                "launches_per_step": r["launches"] / args.steps}
             # the conv instance below the ridge (algorithmic FLOP per byte < 2.5 PF / 8 TB/s) with the largest total time:
             # what it reaches of the HBM roofline, from the same HIP-event timings
-            ridge = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_TBS * 1e12)
             hb = {k: r for k, r in summ.items() if r.get("bytes_total", 0) > 0 and r["flops_total"] / r["bytes_total"] < ridge}
             if hb:
                 hk = max(hb, key=lambda k: hb[k]["ms_total"])
@@ -641,12 +651,17 @@ def main():
                     "avg_launch_us": round(r["ms_total"] / r["launches"] * 1e3, 2),
                     "bytes_per_launch": round(r["bytes_total"] / r["launches"]),
                     "bytes_definition": "algorithmic: inputs + packed weights + output (+ residual), each once"}
-            out["kernels"] = kernels
         if world == 1 and not args.no_secondary and args.stage == 1 and B == 8 and args.dtype == "bf16":
             del timer
             out["secondary"] = secondary_measurements(args, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.stage, S)
+        if timer is not None:
+            # last, and only the heaviest instances: a log tail that is cut still carries secondary / cpu_baseline
+            top = sorted(kernels, key=lambda k: -kernels[k]["ms_per_step"])[:12]
+            out["kernels"] = {k: kernels[k] for k in top}
+            out["kernels_omitted"] = {"instances": len(kernels) - len(top),
+                                      "ms_per_step": round(sum(v["ms_per_step"] for k, v in kernels.items() if k not in top), 3)}
         emit(out)
     if use_dp:
         torch.cuda.synchronize()

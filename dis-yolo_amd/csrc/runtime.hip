@@ -13,15 +13,15 @@ struct Cmd {
   int kind, lane, from, to;
   hipEvent_t ev;
 };
-constexpr int NLANES = 3;   // lane 0 = the caller's stream, lanes 1.. = side streams owned by the list
+constexpr int NLANES = 4;   // lane 0 = the caller's stream, lanes 1.. = side streams owned by the list (3 = the gradient exchange)
 constexpr int NSLOTS = 16;  // named cross-replay marks (cmdlist_mark_slot / cmdlist_wait_slot)
 struct CmdList {
   std::vector<Cmd> cmds;
   hipEvent_t slot_ev[NSLOTS] = {};
   bool slot_recorded[NSLOTS] = {};
-  hipStream_t side[NLANES] = {nullptr, nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[NLANES] = {nullptr, nullptr, nullptr};
-  bool uses[NLANES] = {true, false, false};
+  hipStream_t side[NLANES] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[NLANES] = {};
+  bool uses[NLANES] = {true};
 };
 thread_local CmdList* g_rec = nullptr;
 thread_local int g_lane = 0;
@@ -94,6 +94,7 @@ extern "C" void* disyolo_cmdlist_create(void) {
   // both have blocks pending (+1.5-2 % measured).  DISYOLO_LANE1_LOW=0 keeps it at normal priority
   // (the data-parallel step does: its RCCL all-reduces are issued on this lane).
   // lane 2 carries work that must only fill the other lanes' bubbles (the next step's backbone)
+  // lane 3 carries the data-parallel step's RCCL collectives and the optimizer sweeps behind them (normal priority)
   int least = 0, greatest = 0;
   const char* l1 = getenv("DISYOLO_LANE1_LOW");
   const bool lane1_low = !(l1 && l1[0] == '0');
@@ -199,6 +200,9 @@ extern "C" int disyolo_cmdlist_end(void) {
 }
 extern "C" int disyolo_cmdlist_size(void* l) { return l ? (int)((CmdList*)l)->cmds.size() : DISYOLO_E_ARG; }
 extern "C" void* disyolo_cmdlist_side_stream(void* l) { return l ? (void*)((CmdList*)l)->side[1] : nullptr; }
+extern "C" void* disyolo_cmdlist_lane_stream(void* l, int lane) {
+  return (l && lane >= 1 && lane < NLANES) ? (void*)((CmdList*)l)->side[lane] : nullptr;
+}
 
 extern "C" int disyolo_cmdlist_run(void* l, int first, int last, void* stream) {
   return disyolo_cmdlist_run_ex(l, first, last, stream, 3);

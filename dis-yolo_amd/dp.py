@@ -52,7 +52,8 @@ class GradientAllReduce:
     fully connected xGMI mesh every link then carries 2/world of the bucket instead of a ring's 2(world-1)/world
     per link in sequence.  Unmeasured on hardware until a multi-GPU node runs bench.py."""
 
-    def __init__(self, net, process_group=None, bucket_mb: float = 12.0, wire: str = "f32", algo: str = "allreduce"):
+    def __init__(self, net, process_group=None, bucket_mb: float = 12.0, wire: str = "f32", algo: str = "allreduce",
+                 inlist: bool = False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         if wire not in ("f32", "bf16") or algo not in ("allreduce", "rs_ag"):
@@ -61,6 +62,24 @@ class GradientAllReduce:
         self.pg = process_group
         self.wire, self.algo = wire, algo
         self.world_size = dist.get_world_size(process_group)
+        # inlist: the exchange is a COMMAND of the recorded step (csrc/comm.hip): a communicator owned by the kernel
+        # library, created once from an id rank 0 makes and torch.distributed hands round; the step's slices (the
+        # optimizer's arena slices, net._plan_opt_chunks) are reduced on the list's exchange lane and swept right behind
+        # their collective -- the list is never cut, nothing returns to Python between launches
+        self.inlist = bool(inlist)
+        self.comm = None
+        self._stage_inlist = {}
+        if self.inlist:
+            from . import lib as L
+            rank = dist.get_rank(process_group)
+            src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+
+            def exchange(ident):
+                box = [ident]
+                dist.broadcast_object_list(box, src=src, group=process_group)
+                return box[0]
+            torch.cuda.set_device(net.device)
+            self.comm = L.Comm(rank, self.world_size, exchange)
         spans = []
         for l in net.layers:
             if l.lock:
@@ -137,6 +156,46 @@ class GradientAllReduce:
             self.works.append(dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         self._pending.append((key, o, c))
 
+    def exchange_inlist(self, key, o: int, c: int) -> None:
+        """grad_arena[o:o+c] = its sum over the ranks, as commands of the current lane (or launches on the current
+        stream outside a recording); wire / algo as the cut path's"""
+        from . import lib as L
+        if os.environ.get("DISYOLO_DP_DRY") == "1":
+            return
+        g = self.net.grad_arena[o:o + c]
+        if self.wire == "f32" and self.algo == "allreduce":
+            self.comm.allreduce(g)
+            return
+        st = self._stage_inlist.get(key)
+        if st is None:
+            pad = -(-c // self.world_size) * self.world_size
+            st = torch.zeros(pad, dtype=torch.bfloat16 if self.wire == "bf16" else torch.float32, device=g.device)
+            self._stage_inlist[key] = st
+        if self.wire == "bf16":
+            L.cast_f32_bf16(g, st)
+        else:
+            L.copy2d_f32(g, st, 1, c, c, c)
+        if self.algo == "rs_ag":
+            self.comm.reduce_scatter(st)
+            self.comm.all_gather(st)
+        else:
+            self.comm.allreduce(st)
+        if self.wire == "bf16":
+            L.cast_bf16_f32(st, g)
+        else:
+            L.copy2d_f32(st, g, 1, c, c, c)
+
+    def describe(self):
+        """what bench.py prints as dp_exchange when the exchange is in the list (nothing to wait for on the host)"""
+        net = self.net
+        if net.opt_chunks is None:
+            net._plan_opt_chunks()
+        esz = 2 if self.wire == "bf16" else 4
+        sizes = [ch["cnt"] * esz / 1e6 for ch in reversed(net.opt_chunks)] + [self.tail[1] * esz / 1e6]
+        return {"mode": "commands of the recorded step (RCCL from the kernel library, lane %d)" % 3,
+                "collectives_per_step": len(sizes), "bucket_mb": [round(x, 2) for x in sizes], "wire": self.wire,
+                "algo": self.algo, "list_cuts": 0}
+
     def fire(self, bi: int) -> None:
         _, o, c = self.buckets[bi]
         self._exchange(bi, o, c)
@@ -191,17 +250,24 @@ def broadcast_parameters(net, src: int = 0, process_group=None) -> None:
 
 
 def enable_data_parallel(net, process_group=None, bucket_mb: float = 12.0, wire: Optional[str] = None,
-                         algo: Optional[str] = None, broadcast: bool = True, sync_bn: bool = False) -> GradientAllReduce:
+                         algo: Optional[str] = None, broadcast: bool = True, sync_bn: bool = False,
+                         inlist: Optional[bool] = None) -> GradientAllReduce:
     """wire / algo default to DISYOLO_DP_WIRE / DISYOLO_DP_ALGO (f32 / allreduce).  ``broadcast``: every
     rank starts from rank 0's variables (the reference has one process, hence one initialisation).
     ``sync_bn``: batch-norm statistics (forward moments and the two backward sums) over all ranks' batches,
-    so that N ranks x b images train like one process with N*b images."""
+    so that N ranks x b images train like one process with N*b images.
+    ``inlist``: the exchange as commands of the recorded step (RCCL called from the kernel library, no list cuts);
+    default: on for a CUDA net over an RCCL ("nccl") process group unless DISYOLO_DP_INLIST=0, off otherwise (gloo
+    groups and plan-only CPU nets keep the cut list: torch.distributed issues their collectives)."""
     if getattr(net, "pair", False):
         # the pair step alternates two single-GPU lists and its eager form has no exchange point
         raise DisyoloError("backbone_pair is a single-GPU option: build the net without it for data parallelism")
     wire = wire or os.environ.get("DISYOLO_DP_WIRE", "f32")
     algo = algo or os.environ.get("DISYOLO_DP_ALGO", "allreduce")
-    net.dp = GradientAllReduce(net, process_group, bucket_mb, wire, algo)
+    if inlist is None:
+        inlist = (os.environ.get("DISYOLO_DP_INLIST", "1") != "0" and net.device.type == "cuda"
+                  and not getattr(net, "plan_only", False) and dist.get_backend(process_group) == "nccl")
+    net.dp = GradientAllReduce(net, process_group, bucket_mb, wire, algo, inlist=inlist)
     if broadcast and net.dp.world_size > 1:
         broadcast_parameters(net, 0, process_group)
     if sync_bn:

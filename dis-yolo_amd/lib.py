@@ -149,6 +149,16 @@ _SIGS = {
     "disyolo_cmdlist_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "disyolo_cmdlist_run_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "disyolo_cmdlist_side_stream": (C.c_void_p, [C.c_void_p]),
+    "disyolo_cmdlist_lane_stream": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "disyolo_comm_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
+    "disyolo_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "disyolo_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "disyolo_comm_destroy": (C.c_int, [C.c_void_p]),
+    "disyolo_comm_allreduce_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "disyolo_comm_reduce_scatter_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "disyolo_comm_all_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "disyolo_cast_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "disyolo_cast_bf16_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "disyolo_polygon_mask": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p]),
     "disyolo_aug_place": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
     "disyolo_aug_salt_pepper": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -233,10 +243,16 @@ class CmdList:
         self.h = load().disyolo_cmdlist_create()
         self.keep = []           # tensors / descriptors referenced by the recorded commands
         self._side = None        # side_stream()'s torch wrapper
+        self._lanes = {}
 
     def __del__(self):
         try:
             if self.h:
+                if torch.cuda.is_available() and (self._side is not None or self._lanes):
+                    # a side lane may still be running: the caller's stream waits before streams / buffers are released
+                    for st in [self._side] + list(self._lanes.values()):
+                        if st is not None:
+                            torch.cuda.current_stream(st.device).wait_stream(st)
                 load().disyolo_cmdlist_destroy(self.h)
         except Exception:
             pass
@@ -270,6 +286,14 @@ class CmdList:
         if self._side is None:
             self._side = torch.cuda.ExternalStream(load().disyolo_cmdlist_side_stream(self.h), device=device)
         return self._side
+
+    def lane_stream(self, lane: int, device) -> "torch.cuda.Stream":
+        """lane 1..3 of this list as a torch stream (same ownership as side_stream)"""
+        if lane == 1:
+            return self.side_stream(device)
+        if lane not in self._lanes:
+            self._lanes[lane] = torch.cuda.ExternalStream(load().disyolo_cmdlist_lane_stream(self.h, lane), device=device)
+        return self._lanes[lane]
 
 
 def same_pads(size: int, k: int, s: int):
@@ -997,3 +1021,87 @@ def l2_loss(w, n, l2, out, ws: Workspace) -> None:
     need = load().disyolo_l2_workspace(n)
     buf = ws.get(need)
     _check(load().disyolo_l2_loss(_p(w), n, l2, _p(out), _p(buf), buf.numel(), _stream()), "l2_loss")
+
+
+# ---- gradient exchange as commands of the step (csrc/comm.hip) -------------------------------------------------
+COMM_LANE = 3        # the list's lane that carries the collectives and the optimizer sweeps behind them
+_DT_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float64: 2}
+
+
+def rccl_path() -> Optional[str]:
+    """the RCCL copy this process already maps (torch ships one next to libtorch_hip.so); None = default search"""
+    p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return p if os.path.exists(p) else None
+
+
+def comm_load() -> int:
+    """dlopen RCCL inside the kernel library; returns RCCL's version code.  Raises DisyoloError when it cannot."""
+    p = rccl_path()
+    ver = C.c_int(0)
+    _check(load().disyolo_comm_load(p.encode() if p else None, C.byref(ver)), "comm_load")
+    return ver.value
+
+
+class Comm:
+    """An RCCL communicator owned by the kernel library, one rank per process.  Created collectively: rank 0 makes the
+    128-byte id, ``exchange(id_bytes or None) -> id_bytes`` hands it to every rank (torch.distributed's
+    broadcast_object_list in dp.py -- any backend, used once), then every rank joins.  The collectives are recordable:
+    inside a CmdList recording they become commands of the current lane."""
+
+    def __init__(self, rank: int, world: int, exchange):
+        comm_load()
+        ident = None
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            _check(load().disyolo_comm_unique_id(buf), "comm_unique_id")
+            ident = buf.raw
+        ident = exchange(ident)
+        if not isinstance(ident, (bytes, bytearray)) or len(ident) != 128:
+            raise DisyoloError("Comm: the id exchange must return rank 0's 128 bytes on every rank")
+        h = C.c_void_p()
+        _check(load().disyolo_comm_init(C.create_string_buffer(bytes(ident), 128), rank, world, C.byref(h)), "comm_init")
+        self.h, self.rank, self.world = h, rank, world
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            _check(load().disyolo_comm_destroy(self.h), "comm_destroy")
+            self.h = None
+
+    def allreduce(self, t: torch.Tensor) -> None:
+        """t = sum over the ranks (in place), on the current stream / lane"""
+        if t.dtype not in _DT_CODE or not t.is_cuda or not t.is_contiguous():
+            raise DisyoloError("Comm.allreduce: contiguous CUDA f32 / bf16 / f64 tensor expected")
+        _check(load().disyolo_comm_allreduce_sum(self.h, _p(t), t.numel(), _DT_CODE[t.dtype], _stream()), "comm_allreduce_sum")
+
+    def reduce_scatter(self, full: torch.Tensor) -> torch.Tensor:
+        """in place: this rank's shard of ``full`` (numel a multiple of the world size) = its sum over the ranks;
+        returns the shard view"""
+        n = full.numel() // self.world
+        if n * self.world != full.numel() or full.dtype not in _DT_CODE or not full.is_contiguous():
+            raise DisyoloError("Comm.reduce_scatter: numel must be a multiple of the world size")
+        shard = full.view(-1)[self.rank * n:(self.rank + 1) * n]
+        _check(load().disyolo_comm_reduce_scatter_sum(self.h, _p(full), _p(shard), n, _DT_CODE[full.dtype], _stream()),
+               "comm_reduce_scatter_sum")
+        return shard
+
+    def all_gather(self, full: torch.Tensor) -> None:
+        """in place: every rank's shard of ``full`` to every rank"""
+        n = full.numel() // self.world
+        shard = full.view(-1)[self.rank * n:(self.rank + 1) * n]
+        _check(load().disyolo_comm_all_gather(self.h, _p(shard), _p(full), n, _DT_CODE[full.dtype], _stream()), "comm_all_gather")
+
+
+def cast_f32_bf16(src: torch.Tensor, dst: torch.Tensor) -> None:
+    _need(src, torch.float32, "src")
+    _need(dst, torch.bfloat16, "dst")
+    if dst.numel() < src.numel():
+        raise DisyoloError("cast_f32_bf16: destination shorter than the source")
+    _check(load().disyolo_cast_f32_bf16(_p(src), _p(dst), src.numel(), _stream()), "cast_f32_bf16")
+
+
+def cast_bf16_f32(src: torch.Tensor, dst: torch.Tensor) -> None:
+    _need(src, torch.bfloat16, "src")
+    _need(dst, torch.float32, "dst")
+    if src.numel() < dst.numel():
+        raise DisyoloError("cast_bf16_f32: source shorter than the destination")
+    _check(load().disyolo_cast_bf16_f32(_p(src), _p(dst), dst.numel(), _stream()), "cast_bf16_f32")

@@ -311,6 +311,7 @@ class YOLONet(object):
     def learning_rate(self, value: float) -> None:
         self._lr = float(value)
         if self.lr_dev is not None:
+            self.sync_lanes()        # (an open tail's Adam sweeps still read lr_dev on the side lane)
             self.lr_dev.fill_(self._lr)
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
@@ -821,7 +822,9 @@ class YOLONet(object):
     def _sync_sums(self, t: torch.Tensor) -> None:
         """all-reduce(SUM) of a small f64 tensor over the ranks, ordered on the lane that produced it: issued
         directly in the per-call path, a cut point of the recorded list otherwise (run_program issues it)"""
-        if self._rec is not None:
+        if self.dp.inlist:
+            self.dp.comm.allreduce(t)        # a command of the current lane (a launch on the current stream when not recording)
+        elif self._rec is not None:
             prog, marks = self._rec
             marks.append((prog.size(), ("sync", t, L.CURRENT_LANE)))
         else:
@@ -862,8 +865,18 @@ class YOLONet(object):
             torch.cuda.current_stream().wait_stream(side)
         self._tail_open = False
 
+    def _inputs_free_of_tail(self) -> bool:
+        """overlap_tail: may the caller's stream overwrite the input tensors while the last replay's tail is still open?
+        Every reader of images / labels / boxes / masks / clip windows / RoI permutations sits on the main lane or on the
+        side lane IN FRONT of the mask-loss mark the main lane waits for (compute_losses) -- except the first layer's
+        weight gradient, which reads the images at the very end of the side lane when layer 1 trains (stage 2).  With
+        layer 1 locked the inputs are free as soon as the main lane's part of the replay is done, i.e. for anything
+        the caller's stream does next."""
+        return self._tail_open and self._overlap and self._prog is not None and self.by_idx[1].lock and not self.pair
+
     def _set_inputs(self, images, clip_window, half: int = 0) -> None:
-        self.sync_lanes()
+        if not self._inputs_free_of_tail():
+            self.sync_lanes()
         images = torch.as_tensor(images)
         if tuple(images.shape) != (self.B, self.S, self.S, 3):
             raise ValueError("images must be [%d,%d,%d,3] NHWC (batch size and image size are baked into the plan, "
@@ -1083,8 +1096,10 @@ class YOLONet(object):
         final_of = self._final_writers(visit) if fuse_bn else {}
         for l in self.layers:
             l.bwd_part_rows = 0
-        # (data parallelism: the sweep must follow the bucket's all-reduce -- it stays in optimizer_step)
-        overlap_opt = sweep and self.dp is None and self.n_params > 0 and os.environ.get("DISYOLO_OPT_OVERLAP", "1") != "0"
+        # (data parallelism with a cut list: the sweep must follow the bucket's all-reduce -- it stays in optimizer_step;
+        # with the exchange in the list the slice's all-reduce and its sweep go to the exchange lane together)
+        inl = self.dp is not None and self.dp.inlist
+        overlap_opt = sweep and (self.dp is None or inl) and self.n_params > 0 and os.environ.get("DISYOLO_OPT_OVERLAP", "1") != "0"
         if overlap_opt:
             if self.opt_chunks is None:
                 self._plan_opt_chunks()
@@ -1207,14 +1222,25 @@ class YOLONet(object):
                 ci = self._opt_chunk_of[l.idx]
                 self._opt_done[ci].add(l.idx)
                 if self._opt_done[ci] == self.opt_chunks[ci]["members"]:
-                    L.lane_wait(L.lane_mark(0), 1)
-                    L.set_lane(1)
-                    self._sweep_chunk(ci, 1.0)
+                    if inl:
+                        # data parallel: the slice's gradients are summed over the ranks first.  Collective + sweep +
+                        # re-pack on the exchange lane, behind the side lane's weight gradients of the slice and the
+                        # main lane up to here: the side lane goes on with the next layers' weight gradients meanwhile
+                        L.lane_wait(L.lane_mark(1), L.COMM_LANE)
+                        L.lane_wait(L.lane_mark(0), L.COMM_LANE)
+                        L.set_lane(L.COMM_LANE)
+                        self._sweep_chunk(ci, 1.0 / self.dp.world_size)
+                    else:
+                        L.lane_wait(L.lane_mark(0), 1)
+                        L.set_lane(1)
+                        self._sweep_chunk(ci, 1.0)
                     L.set_lane(0)
             if on_layer_done is not None:
                 on_layer_done(l)
         if not self._overlap_rec:
             L.lane_sync(1, 0)
+            if inl:
+                L.lane_sync(L.COMM_LANE, 0)
 
     def _apply_tiles(self) -> None:
         """rebuild everything that depends on a tile choice: batch-norm partial-sum buffers
@@ -1326,6 +1352,8 @@ class YOLONet(object):
         """Adam over slice ci + the re-pack of its layers"""
         ch = self.opt_chunks[ci]
         o, c = ch["off"], ch["cnt"]
+        if self.dp is not None and self.dp.inlist:
+            self.dp.exchange_inlist(ci, o, c)
         L.adam_sweep(self.arena[o:o + c], self.grad_arena[o:o + c], self.adam_m[o:o + c], self.adam_v[o:o + c], c, c,
                      self.lr_dev, cfg.ADAM_BETA1, cfg.ADAM_BETA2, cfg.ADAM_EPSILON, self.l2, self.step_dev, grad_scale,
                      self._opt_parts[ch["parts_off"]:ch["parts_off"] + ch["nparts"]])
@@ -1348,6 +1376,8 @@ class YOLONet(object):
             nt = self.n_params - self.n_decay       # batch-norm gamma / beta: not regularised
             if nt > 0:
                 o = self.n_decay
+                if self.dp is not None and self.dp.inlist:
+                    self.dp.exchange_inlist("tail", o, nt)
                 L.adam_sweep(self.arena[o:], self.grad_arena[o:], self.adam_m[o:], self.adam_v[o:], nt, 0, self.lr_dev,
                              cfg.ADAM_BETA1, cfg.ADAM_BETA2, cfg.ADAM_EPSILON, self.l2, self.step_dev, grad_scale, None)
             L.adam_finish(self.step_dev, self._opt_parts if self.n_decay else None, self._opt_nparts if self.n_decay else 0,
@@ -1391,6 +1421,7 @@ class YOLONet(object):
         """
         if not self.training:
             raise L.DisyoloError("build_program on a YOLONet built with training=False")
+        self.sync_lanes()            # (a previous list's tail may still run: join before that list is dropped)
         # ``overlap_tail`` (single GPU, list executor): the step does not join its side lane at the end.  The side lane still
         # owes the optimizer sweeps of the slices that became final last (three quarters of the stage-1 parameters sit in the
         # layers the backward pass reaches last) and the last weight gradients -- 0.15 ms during which the main lane was idle;
@@ -1398,8 +1429,10 @@ class YOLONet(object):
         # still reads it (the weight gradients of the layers fed by backbone outputs) and, in front of the first trainable
         # layer, for the optimizer + re-pack.  Same kernels, same order per lane: results bit-identical.  train_step(want_loss=
         # True), total_loss(), forward(), set_batch(), state_dict() ... join first (sync_lanes()).
-        if overlap_tail and (graph or pipeline_backbone or self.pair or self.dp is not None or not self.use_side_lane):
-            raise L.DisyoloError("overlap_tail needs the single-GPU two-lane list executor (no graph / pipeline / pair / dp)")
+        if overlap_tail and (graph or pipeline_backbone or self.pair or (self.dp is not None and not self.dp.inlist)
+                             or not self.use_side_lane):
+            raise L.DisyoloError("overlap_tail needs the two-lane list executor (no graph / pipeline / pair; data parallelism "
+                                 "only with the exchange in the list)")
         self._overlap = bool(overlap_tail)
         if self._overlap:
             self._plan_overlap()
@@ -1463,14 +1496,15 @@ class YOLONet(object):
     def _record_step(self, det_thresh: float, parity):
         """one recorded step; parity None = plain, 0/1 = pipelined (consumes backbone outputs of
         that parity, produces the other)"""
-        if self.dp is not None:
+        inl = self.dp is not None and self.dp.inlist
+        if self.dp is not None and not inl:
             # the RCCL all-reduces are issued on the side lane: keep it at normal stream priority
             os.environ.setdefault("DISYOLO_LANE1_LOW", "0")
         prog = L.CmdList()
         marks = []
         if self.sync_bn and parity is not None:
             raise L.DisyoloError("SyncBN is not wired for the pipelined-backbone step")
-        self._rec = (prog, marks) if self.dp is not None else None
+        self._rec = (prog, marks) if (self.dp is not None and not inl) else None
         with prog:
             first = 1
             if parity is not None:
@@ -1489,7 +1523,7 @@ class YOLONet(object):
                 self._forward_prefix(self._pipe_P, True)
                 L.set_lane(0)
                 self._use_parity(parity)
-            if self.dp is not None:
+            if self.dp is not None and not inl:
                 self.dp.begin_step()
 
                 def mark(l):
@@ -1507,9 +1541,16 @@ class YOLONet(object):
             if self._overlap_rec:
                 # what is left of the optimizer (the slices that became final last, gamma / beta, the finish) stays on the side
                 # lane behind the last weight gradients; it needs the main lane's last batch-norm gradients
-                L.lane_wait(L.lane_mark(0), 1)
-                L.set_lane(1)
-                self.optimizer_step(1.0)
+                # (data parallel: on the exchange lane, each sweep behind its slice's collective; the side lane then waits
+                # for the exchange lane, so "the end of the side lane" still means "the step is complete")
+                tl = L.COMM_LANE if inl else 1
+                L.lane_wait(L.lane_mark(0), tl)
+                if inl:
+                    L.lane_wait(L.lane_mark(1), tl)
+                L.set_lane(tl)
+                self.optimizer_step(1.0 / self.dp.world_size if inl else 1.0)
+                if inl:
+                    L.lane_sync(tl, 1)
                 L.lane_mark_slot(1, self.SLOT_ALL)
                 L.set_lane(0)
             else:
@@ -1523,7 +1564,7 @@ class YOLONet(object):
         if self._graph is not None:
             self._graph.replay()
             return
-        if self.dp is None or os.environ.get("DISYOLO_DP_NOSEG") == "1":
+        if self.dp is None or self.dp.inlist or os.environ.get("DISYOLO_DP_NOSEG") == "1":
             self._prog.run(join=not self._overlap)
             self._tail_open = self._overlap
             return
@@ -1584,7 +1625,10 @@ class YOLONet(object):
             self._use_half(1 - self._half)
             return loss
         self.compute_losses(det_thresh)
-        if self.dp is not None:
+        if self.dp is not None and self.dp.inlist:
+            self.backward(sweep=True)       # (every slice's collective is issued in front of its sweep)
+            self.optimizer_step(1.0 / self.dp.world_size)
+        elif self.dp is not None:
             self.dp.begin_step()
             self.backward(self.dp.on_layer_done)
             self.dp.finish()

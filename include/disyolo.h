@@ -472,7 +472,7 @@ void disyolo_cmdlist_destroy(void* list);
 int disyolo_cmdlist_begin(void* list);
 int disyolo_cmdlist_end(void);
 int disyolo_cmdlist_size(void* list);
-/* three lanes: 0 = the stream passed to cmdlist_run, 1 and 2 = side streams owned by the list.
+/* four lanes: 0 = the stream passed to cmdlist_run, 1..3 = side streams owned by the list (3 = the gradient exchange).
  * set_lane selects the lane of the launches recorded next; sync(from,to) makes lane `to` wait
  * for what lane `from` has recorded so far.  Both are no-ops outside a recording.  Every
  * cmdlist_run range forks the side lane after the caller's stream and joins it at the end. */
@@ -493,6 +493,28 @@ int disyolo_cmdlist_run(void* list, int first, int last, void* stream);
  * order other work (an RCCL all-reduce) after the side lane only */
 int disyolo_cmdlist_run_ex(void* list, int first, int last, void* stream, int flags);
 void* disyolo_cmdlist_side_stream(void* list);
+void* disyolo_cmdlist_lane_stream(void* list, int lane);   /* lane 1..3 (side_stream = lane 1) */
+
+/* ---- data-parallel gradient exchange as COMMANDS of the step (csrc/comm.hip) ----
+ * The reference trains on one GPU (yolo/config.py:18; the op being distributed is train_yolo3_mask.py:55-56,
+ * AdamOptimizer.minimize(total_loss)): every loss term is a per-image sum averaged over the batch
+ * (yolo/yolo3_net_pos.py:692-726,858), so N ranks with equal local batches exchange ONE thing per step -- the sum of
+ * their gradients.  These entry points put that exchange on RCCL (xGMI) without leaving the command list: inside a
+ * recording a collective is a command of the current lane like any launch.
+ * comm_load: dlopen RCCL (path NULL = default search; the host binding passes the copy the process already maps);
+ *   no link-time dependency.  comm_unique_id (rank 0) -> 128 opaque bytes, exchanged by the host out of band ->
+ *   comm_init on every rank (a collective; the current HIP device is the rank's GPU) -> an opaque communicator.
+ * dtype: 0 = f32, 1 = bf16, 2 = f64.  Every rank must issue the same collectives in the same order. */
+int disyolo_comm_load(const char* rccl_path, int* version);
+int disyolo_comm_unique_id(void* id128);
+int disyolo_comm_init(const void* id128, int rank, int nranks, void** comm);
+int disyolo_comm_destroy(void* comm);
+int disyolo_comm_allreduce_sum(void* comm, void* buf, int64_t count, int dtype, void* stream);
+int disyolo_comm_reduce_scatter_sum(void* comm, const void* send, void* recv, int64_t recvcount, int dtype, void* stream);
+int disyolo_comm_all_gather(void* comm, const void* send, void* recv, int64_t sendcount, int dtype, void* stream);
+/* wire-format conversions of a gradient bucket (bf16 on the links, round to nearest even): any n > 0 */
+int disyolo_cast_f32_bf16(const void* src_f32, void* dst_bf16, int64_t n, void* stream);
+int disyolo_cast_bf16_f32(const void* src_bf16, void* dst_f32, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

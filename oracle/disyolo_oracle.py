@@ -451,12 +451,15 @@ def non_max_suppression(boxes: np.ndarray, scores: np.ndarray, max_out: int, iou
 
 
 def filter_detections(conf_logit, class_logit, pred_norm_coord, batch_window, obj_thresh=OBJ_THRESHOLD,
-                      nms_thresh=IOU_THRESHOLD, max_detection=MAX_DETECTION) -> np.ndarray:
+                      nms_thresh=IOU_THRESHOLD, max_detection=MAX_DETECTION, return_index: bool = False):
     """yolo/yolo3_net_pos.py:517-628.  Returns float32 [B, max_detection, 6]
     rows (y1,x1,y2,x2,classid,score), score-descending, zero padded.  All scoring
-    arithmetic is done in f32 like the reference graph."""
+    arithmetic is done in f32 like the reference graph.  ``return_index`` (test aid, not in the
+    reference): also the candidate index of every row (position in the 72,36,18-grid concatenation
+    of :527-538, each grid flattened (y, x, anchor)), -1 where padded."""
     B = conf_logit[0].shape[0]
     out = np.zeros((B, max_detection, 6), dtype=np.float32)
+    out_idx = np.full((B, max_detection), -1, dtype=np.int64)
     for i in range(B):
         confs, clss, boxes = [], [], []
         for j in (0, 1, 2):                                             # :527-538 order 72,36,18
@@ -487,7 +490,8 @@ def filter_detections(conf_logit, class_logit, pred_norm_coord, batch_window, ob
             out[i, r, :4] = yxyx[idx]
             out[i, r, 4] = np.float32(classid[idx])
             out[i, r, 5] = score[idx]
-    return out
+            out_idx[i, r] = idx
+    return (out, out_idx) if return_index else out
 
 
 # ---------------------------------------------------------------------------

@@ -185,8 +185,11 @@ def one_rank_rccl(dev):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("inlist", [True, False])
 @pytest.mark.parametrize("pipeline", [False, True])
-def test_config2_one_rank_rccl_step_equals_plain_step(dev, one_rank_rccl, pipeline):
+def test_config2_one_rank_rccl_step_equals_plain_step(dev, one_rank_rccl, pipeline, inlist):
+    """inlist: the gradient exchange as commands of the recorded step (csrc/comm.hip, the default on RCCL groups);
+    False: the list cut at the bucket boundaries, torch.distributed issuing the collectives"""
     from disyolo_amd.dp import enable_data_parallel
     B, S = 2, 64
     batches = [O.synthetic_batch(B, S, seed=60 + t) for t in range(4)]
@@ -195,9 +198,10 @@ def test_config2_one_rank_rccl_step_equals_plain_step(dev, one_rank_rccl, pipeli
         seeded_heads(n, 31, gain=6.0, bias_std=0.5)
         n.shuffle_seed = 17
     dp_eager, dp_prog, plain = nets
-    enable_data_parallel(dp_eager, bucket_mb=4.0)
-    enable_data_parallel(dp_prog, bucket_mb=4.0)
-    assert len(dp_prog.dp.buckets) >= 3                      # several cuts of the recorded step
+    enable_data_parallel(dp_eager, bucket_mb=4.0, inlist=inlist)
+    enable_data_parallel(dp_prog, bucket_mb=4.0, inlist=inlist)
+    assert dp_prog.dp.inlist == inlist and (dp_prog.dp.comm is not None) == inlist
+    assert len(dp_prog.dp.buckets) >= 3                      # several cuts of the recorded step (cut form)
     plain.build_program(det_thresh=0.1, pipeline_backbone=pipeline)
     dp_prog.build_program(det_thresh=0.1, pipeline_backbone=pipeline)
     if pipeline:
@@ -217,14 +221,51 @@ def test_config2_one_rank_rccl_step_equals_plain_step(dev, one_rank_rccl, pipeli
             losses[k].append(float(n.train_step(None).cpu()))
     torch.cuda.synchronize()
     assert losses[0] == losses[1] == losses[2]
+    assert (len(dp_prog._prog_marks) == 0) == inlist         # the in-list exchange leaves the list uncut
     for n in (dp_eager, dp_prog):
         assert torch.equal(n.arena, plain.arena) and torch.equal(n.adam_m, plain.adam_m) and torch.equal(n.adam_v, plain.adam_v)
         for name in plain.params:
             assert torch.equal(n.params[name], plain.params[name]), name
 
 
+@pytest.mark.parametrize("sync_bn", [False, True])
+def test_config2_exchange_in_the_list_with_the_overlapped_tail(dev, one_rank_rccl, sync_bn):
+    """the data-parallel step as bench.py runs it since round 5: collectives recorded on the list's exchange lane, each
+    slice's optimizer sweep right behind its all-reduce, the tail left open into the next replay (overlap_tail) --
+    against the plain joined single-GPU step on the same batches, bit for bit; un-joined replays in between.  With
+    SyncBN the per-layer statistics all-reduces are commands of the lane that produced the sums."""
+    from disyolo_amd.dp import enable_data_parallel
+    B, S = 2, 64
+    batches = [O.synthetic_batch(B, S, seed=80 + t) for t in range(5)]
+    nets = [YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=1, seed=3) for _ in range(2)]
+    for n in nets:
+        seeded_heads(n, 31, gain=6.0, bias_std=0.5)
+        n.shuffle_seed = 17
+        n.set_batch(batches[0])
+    plain, dpn = nets
+    enable_data_parallel(dpn, inlist=True, sync_bn=sync_bn)
+    plain.build_program(det_thresh=0.1)
+    dpn.build_program(det_thresh=0.1, overlap_tail=True)
+    assert dpn._prog_marks == [] and dpn._overlap
+    for t in range(5):
+        plain.set_batch(batches[t])
+        dpn.set_batch(batches[t])
+        assert t == 0 or dpn._tail_open
+        plain.train_step(None, want_loss=False)
+        dpn.train_step(None, want_loss=False)
+    l0, l1 = float(plain.total_loss().cpu()), float(dpn.total_loss().cpu())
+    torch.cuda.synchronize()
+    assert l0 == l1
+    assert torch.equal(dpn.arena, plain.arena) and torch.equal(dpn.adam_m, plain.adam_m) and torch.equal(dpn.adam_v, plain.adam_v)
+    for name in plain.params:
+        assert torch.equal(dpn.params[name], plain.params[name]), name
+    d = dpn.dp.describe()
+    assert d["list_cuts"] == 0 and d["collectives_per_step"] == len(dpn.opt_chunks) + 1
+
+
+@pytest.mark.parametrize("inlist", [True, False])
 @pytest.mark.parametrize("wire,algo", [("f32", "rs_ag"), ("bf16", "allreduce"), ("bf16", "rs_ag")])
-def test_config2_wire_formats_and_reduce_scatter_variant(dev, one_rank_rccl, wire, algo):
+def test_config2_wire_formats_and_reduce_scatter_variant(dev, one_rank_rccl, wire, algo, inlist):
     """the exchange options of dp.py on one RCCL rank: reduce-scatter + all-gather of an f32 bucket is the
     identity (bit-identical step); the bf16 wire rounds the gradient to 8 significant bits once, so after
     one Adam step (|dw| <= lr) the weights agree to a fraction of lr"""
@@ -237,7 +278,7 @@ def test_config2_wire_formats_and_reduce_scatter_variant(dev, one_rank_rccl, wir
         n.shuffle_seed = 5
         n.set_batch(batch)
     plain, dpn = nets
-    enable_data_parallel(dpn, bucket_mb=4.0, wire=wire, algo=algo)
+    enable_data_parallel(dpn, bucket_mb=4.0, wire=wire, algo=algo, inlist=inlist)
     plain.build_program(det_thresh=0.1)
     dpn.build_program(det_thresh=0.1)
     # bf16 wire: ONE step (from identical weights); the rounded gradients change the weights in the last
@@ -258,7 +299,8 @@ def test_config2_wire_formats_and_reduce_scatter_variant(dev, one_rank_rccl, wir
         assert float(dw.max()) < 0.5 * cfg.LEARNING_RATE, info
 
 
-def test_sync_bn_on_one_rank_is_the_plain_step(dev, one_rank_rccl):
+@pytest.mark.parametrize("inlist", [True, False])
+def test_sync_bn_on_one_rank_is_the_plain_step(dev, one_rank_rccl, inlist):
     """SyncBN with a single rank: the all-reduces are identities, the statistics go through the split
     (partial rows -> f64 sums -> finalize) kernels instead of the fused ones -- same arithmetic, so the
     recorded step must reproduce the plain step bit for bit (eager and recorded)."""
@@ -271,11 +313,12 @@ def test_sync_bn_on_one_rank_is_the_plain_step(dev, one_rank_rccl):
         n.shuffle_seed = 5
         n.set_batch(batch)
     plain, sync_eager, sync_prog = nets
-    enable_data_parallel(sync_eager, bucket_mb=4.0, sync_bn=True)
-    enable_data_parallel(sync_prog, bucket_mb=4.0, sync_bn=True)
+    enable_data_parallel(sync_eager, bucket_mb=4.0, sync_bn=True, inlist=inlist)
+    enable_data_parallel(sync_prog, bucket_mb=4.0, sync_bn=True, inlist=inlist)
     plain.build_program(det_thresh=0.1)
     sync_prog.build_program(det_thresh=0.1)
-    assert any(isinstance(w, tuple) for _, w in sync_prog._prog_marks)       # the recorded list is cut at the statistics
+    # cut form: the recorded list is cut at the statistics; in-list form: their all-reduces are commands, no cut
+    assert any(isinstance(w, tuple) for _, w in sync_prog._prog_marks) != inlist
     for _ in range(2):
         ls = [float(n.train_step(None, det_thresh=0.1).cpu()) for n in (plain, sync_eager, sync_prog)]
         assert ls[0] == ls[1] == ls[2]

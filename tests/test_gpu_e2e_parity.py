@@ -2,16 +2,20 @@
 inputs within a stated fp tolerance" -- the HIP inference path (bf16 storage) against the f32 oracle on a TRAINED net
 at the BASELINE sizes, detection by detection (calculate_test_map.py:218-266 consumes exactly these arrays).
 
-The stated tolerance (measured in profiles/r04_e2e_parity.json):
-  * >= 90 % of the f32 oracle's detections are found with the same class and box IoU >= 0.75, every one of them
+The stated tolerance (measured in profiles/r05_e2e_parity.json: the per-pair table):
+  * >= 95 % of the f32 oracle's detections are found with the same class and box IoU >= 0.75, every one of them
     that is not within 0.1 of the score threshold bar at most one per batch (an NMS survivor can flip between two
     near-duplicate candidates);
-  * >= 65 % with box IoU >= 0.9 (a 1 % logit error is 5 % of a box side through anchor * exp(t));
-  * pairs matched at IoU >= 0.9: |score difference| <= 0.12 for all but at most ONE pair of the batch (<= 0.3: a detection whose
-    confidence logit sits where the sigmoid is steep -- the net was fitted THROUGH the bf16 forward pass, the f32 oracle evaluating
-    the same variables sees confidence logits ~1 lower at the detected cells; how many such detections a net has depends on how far
-    its 3,000-step overfit got, the bf16-emulating oracle shows 0.18 on the same variables), median <= 0.06; mask IoU after "> 0.5"
-    >= 0.8 each, >= 0.93 on average;
+  * >= 90 % with box IoU >= 0.9 (measured: 97 ... 100 %; rounds 1-4 stated 65 % -- on a fixture that had memorised the
+    rounding pattern of its own training pass, see e2e_parity.train_overfit);
+  * pairs matched at IoU >= 0.9: |score difference| <= 0.12 for EVERY pair, except a pair the bf16-emulating oracle moves as
+    well: there the bar is 1.5 x |score(bf16 oracle) - score(f32 oracle)| AT THAT DETECTION'S OWN CANDIDATE + 0.03 (the net was fitted
+    THROUGH the bf16 forward pass; where the f32 oracle sees a confidence logit on the steep part of the sigmoid, bf16 storage
+    itself -- whoever implements it -- moves the score); median <= 0.02; mask IoU after "> 0.5" >= 0.85 each, >= 0.95 on average;
+  * at the grid cell + anchor of EVERY detection of the f32 oracle, the raw head outputs (pre-sigmoid t_xy, t_wh, confidence
+    logit, class logits): |HIP - f32| <= 1.5 x |bf16 oracle - f32| + eps, eps = 0.15 / 0.05 / 0.25 / 0.2 (e2e_parity.EPS: what
+    two bf16 evaluations with different summation orders differ by between themselves at a detected cell);
+  * two fixtures per size (two seeds, two overfit lengths), so no bar is calibrated on one training trajectory;
   * and the yardstick: the oracle itself with every stored tensor rounded to bf16 reproduces the f32 oracle no
     better than the HIP path does (within 0.1 of its IoU-0.75 rate) -- the gap is bf16 storage, not the kernels.
 The oracle is pinned by hand KATs only (TF 1.x cannot run here): "parity unpinned" applies to this file too."""
@@ -24,43 +28,45 @@ import torch
 import e2e_parity as E
 
 pytestmark = pytest.mark.gpu
-STEPS = 3000
 THR = 0.25            # cfg.OBJ_THRESHOLD, the value evaluate() passes
+# (image size, batch, batch seed, overfit steps): two trajectories per size
+FIXTURES = [(576, 8, 5, 3000), (576, 8, 7, 2000), (832, 4, 5, 3000), (832, 4, 7, 2000)]
 
 
 @pytest.fixture(scope="module")
 def trained(dev):
     out = {}
-    for S, B in ((576, 8), (832, 4)):
-        batch = E.painted_batch(B, S, seed=5)
-        sd, curve = E.train_overfit(dev, batch, B, S, STEPS)
+    for S, B, seed, steps in FIXTURES:
+        batch = E.painted_batch(B, S, seed=seed)
+        sd, curve = E.train_overfit(dev, batch, B, S, steps)
         assert curve[-1] < 0.01 * curve[0] and all(c == c for c in curve), curve      # the recorded step really trained it
-        out[S] = (batch, sd)
+        out[(S, seed)] = (batch, sd, E.oracle_pair(sd, batch["images"], batch["clip_window"], THR))
     return out
 
 
-def _gate(r, yardstick=None):
-    v = r["vs_f32"]
+def _gate(r):
+    v, yardstick = r["vs_f32"], r["bf16_vs_f32"]
     assert v["ref_detections"] >= 3, v                                   # a trained detector, not an empty comparison
-    assert v["reproduced_iou75_frac"] >= 0.9, v
+    assert v["reproduced_iou75_frac"] >= 0.95, v
     assert v["confident_reproduced_iou75"] >= v["confident_ref"] - 1, v
-    assert v["reproduced_iou90_frac"] >= 0.65, v
-    assert v["score_absdiff_2nd"] <= 0.12 and v["score_absdiff_max"] <= 0.3 and v["score_absdiff_median"] <= 0.06, v
-    assert v["mask_iou_min"] >= 0.8 and v["mask_iou_mean"] >= 0.93, v
-    assert v["hip_unmatched"] <= max(1, 0.35 * v["hip_detections"]), v
-    assert max(v["logit_rel_l2"][:3]) < 3e-2 and v["logit_rel_l2"][3] < 0.2, v
-    if yardstick is not None:
-        assert v["reproduced_iou75_frac"] >= yardstick["reproduced_iou75_frac"] - 0.1, (v, yardstick)
+    assert v["reproduced_iou90_frac"] >= 0.9, v
+    assert v["score_absdiff_median"] <= 0.02, v
+    assert v["mask_iou_min"] >= 0.85 and v["mask_iou_mean"] >= 0.95, v
+    assert v["hip_unmatched"] <= max(1, 0.1 * v["hip_detections"]), v
+    assert max(v["logit_rel_l2"][:3]) < 2e-2 and v["logit_rel_l2"][3] < 0.12, v
+    assert v["reproduced_iou75_frac"] >= yardstick["reproduced_iou75_frac"] - 0.1, (v, yardstick)
+    # detection by detection: raw head outputs at the oracle's own candidate, and the matched pair's score, against the
+    # yardstick of THE SAME detection
+    assert not r["pair_violations"], r["pair_violations"]
 
 
-@pytest.mark.parametrize("S,Bi", [(576, 8), (576, 1), (832, 4)])
-def test_detections_and_masks_agree_with_the_f32_oracle(dev, trained, S, Bi):
-    batch, sd = trained[S]
-    r = E.compare(dev, sd, batch["images"][:Bi], batch["clip_window"][:Bi], S, THR, with_bf16_oracle=(Bi > 1))
+@pytest.mark.parametrize("S,Bi,seed", [(576, 8, 5), (576, 1, 5), (576, 8, 7), (832, 4, 5), (832, 1, 5), (832, 4, 7)])
+def test_detections_and_masks_agree_with_the_f32_oracle(dev, trained, S, Bi, seed):
+    batch, sd, oracle = trained[(S, seed)]
+    r = E.compare(dev, sd, batch["images"][:Bi], batch["clip_window"][:Bi], S, THR, oracle=oracle)
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(r, open("gpurun_out/e2e_parity_S%d_B%d.json" % (S, Bi), "w"), indent=1)
-    _gate(r, r.get("bf16_vs_f32"))
-    if "vs_bf16" in r:
-        # against the bf16-emulating oracle (same roundings, another summation order): the same bars
-        q = r["vs_bf16"]
-        assert q["reproduced_iou75_frac"] >= 0.85 and q["mask_iou_mean"] >= 0.93, q
+    json.dump(r, open("gpurun_out/e2e_parity_S%d_B%d_seed%d.json" % (S, Bi, seed), "w"), indent=1)
+    _gate(r)
+    # against the bf16-emulating oracle (same roundings, another summation order): the same bars
+    q = r["vs_bf16"]
+    assert q["reproduced_iou75_frac"] >= 0.9 and q["mask_iou_mean"] >= 0.95, q
