@@ -22,8 +22,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # RCCL creates enough streams to use up ROCm's default 4 hardware queues; the step's side lane
 # then shares a queue with the main lane and the two stop overlapping (1416 -> 1215 img/s on
-# one MI355X).  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# one MI355X).  Round 5: with the exchange lane and a second communicator, 8 queues map two of the
+# step's lanes onto one queue (4.1 -> 10.2 ms per step; 6, 10, 12 ... 32 are fine: profiles/r05_hw_queues.txt).
+# Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 import numpy as np
 import torch
@@ -309,6 +311,18 @@ def secondary_measurements(args, dev):
                                "conv_tiles": d["config"].get("conv_tiles"), "process": "child"}
     except Exception as e:   # a secondary line must never cost the headline
         out["train_stage2"] = {"error": repr(e)[:200]}
+    # the headline workload the way a training loop runs it: a new batch before every step (device-to-device set_batch
+    # inside the timed region; the overlapped tail stays open across it -- nothing in the tail reads an input tensor)
+    if args.stage == 1 and args.dtype == "bf16":
+        try:
+            d = child(["--stage", "1", "--batch", str(args.batch), "--feed", "per-step"])
+            out["train_stage1_feed_per_step"] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
+                                                 "ms_per_step": d["ms_per_step"], "steps": d["steps"], "repeats": d.get("repeats"),
+                                                 "what": d["config"].get("feed"), "step_overlap": bool(d["config"].get("step_overlap")),
+                                                 "loss_first": d["config"].get("loss_first"), "loss_last": d["config"].get("loss_last"),
+                                                 "process": "child"}
+        except Exception as e:
+            out["train_stage1_feed_per_step"] = {"error": repr(e)[:200]}
     # the same stage-1 workload with the locked backbone batched over two steps (an option of the training loop, not the
     # headline: every step still trains on its own batch and every image passes every layer exactly once)
     if args.stage == 1 and args.dtype == "bf16":
@@ -403,6 +417,10 @@ def main():
     ap.add_argument("--poison", action="store_true",
                     help="self-test of the loss canary: a NaN is written into one trainable weight before the timed "
                          "regions; the run must then FAIL (exit code 3, an \"error\" field, no throughput)")
+    ap.add_argument("--feed", default="resident", choices=("resident", "per-step"),
+                    help="resident (the contract: inputs in HBM when the timed region starts, every step replays them) or "
+                         "per-step: what a training loop does -- a NEW batch before every step (two device-resident batches "
+                         "alternate; set_batch's device-to-device copies are inside the timed region)")
     ap.add_argument("--force-dp", action="store_true",
                     help="initialise RCCL and run the bucketed gradient all-reduce path even with one rank (self-test)")
     ap.add_argument("--sync-bn", action="store_true",
@@ -474,7 +492,18 @@ def main():
 
     n_trained = [0]
 
+    feed_sets = None
+    if args.feed == "per-step":
+        if args.pair:
+            raise SystemExit("--feed per-step is not wired for --pair")
+        feed_sets = []
+        for q in range(2):
+            hb = synthetic_batch(B, S, seed=1234 + rank + 7000 * q)
+            feed_sets.append({k: (torch.as_tensor(v).to(dev) if v is not None else None) for k, v in hb.items()})
+
     def step():
+        if feed_sets is not None:
+            net.set_batch(feed_sets[n_trained[0] & 1])
         net.train_step(None, want_loss=False)
         n_trained[0] += 1
 
@@ -573,6 +602,8 @@ def main():
                        # the reference fetches total_loss with every step (train_yolo3_mask.py:216); here the loss stays on
                        # the device inside the timed regions and is read between them (loss_first / loss_last)
                        "loss_fetched_in_timed_region": False,
+                       "feed": ("resident inputs replayed every step" if feed_sets is None else
+                                "a new batch before every step (two device-resident batches alternate; set_batch inside the timed region)"),
                        "box": box},
             "parity": {"status": "partial: oracle unpinned against TF1.x (no TF, no reference vectors for the graph)",
                        "end_to_end_tolerance": "HIP inference vs f32 oracle on nets trained with per-step input jitter (2 seeds x 2 lengths) at 576^2 B=8/B=1 and "

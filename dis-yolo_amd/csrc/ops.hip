@@ -447,9 +447,13 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* w, const float* 
     if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
   }
 }
+// ring != NULL: the step's total loss -- (losses8[7] + mask_loss[0]) + reg, f32, the order YOLONet.total_loss() adds them in --
+// goes to ring[t % ring_len], t = the counter BEFORE the increment (the 0-based index of the step that just finished)
 __global__ __launch_bounds__(256) void adam_fused_tail_kernel(int64_t* counter, const float* part, int nb, float coef,
-                                                              float* reg_out) {
+                                                              float* reg_out, const float* losses8, const float* mask_loss,
+                                                              const float* reg_in, float* ring, int ring_len) {
   __shared__ double sh[4];
+  float reg = reg_in ? reg_in[0] : 0.f;
   if (part && reg_out) {
     double s = 0.0;
     for (int i = threadIdx.x; i < nb; i += 256) s += (double)part[i];
@@ -457,9 +461,15 @@ __global__ __launch_bounds__(256) void adam_fused_tail_kernel(int64_t* counter, 
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) reg_out[0] = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) * coef);
+    if (threadIdx.x == 0) {
+      reg = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) * coef);
+      reg_out[0] = reg;
+    }
   }
-  if (threadIdx.x == 0) *counter += 1;
+  if (threadIdx.x == 0) {
+    if (ring) ring[(int)(*counter % ring_len)] = (losses8[7] + mask_loss[0]) + reg;
+    *counter += 1;
+  }
 }
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* w, int64_t n, float* part) {
@@ -665,7 +675,26 @@ extern "C" int disyolo_adam_finish(int64_t* step_counter, const float* parts, in
   DY_REQUIRE(step_counter && nparts >= 0 && (!reg_loss_out || (parts && nparts > 0)), "adam_finish: bad args");
   DY_RECORD_OR_RUN([=](void* s) { return disyolo_adam_finish(step_counter, parts, nparts, l2, reg_loss_out, s); });
   hipLaunchKernelGGL(adam_fused_tail_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, step_counter, parts, nparts,
-                     0.5f * l2, reg_loss_out);
+                     0.5f * l2, reg_loss_out, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     (float*)nullptr, 1);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+// the finish + the step's total loss into a ring the host reads LATER (a training loop that fetches the loss of every
+// step -- train_yolo3_mask.py:216 does -- otherwise joins the device once per step): ring[t % ring_len] = (losses8[7] +
+// mask_loss[0]) + reg, reg = the l2 term this finish just summed (reg_loss_out) or, when it sums none, reg_loss_in[0]
+// (NULL: 0); t = the step counter before its increment
+extern "C" int disyolo_adam_finish_record(int64_t* step_counter, const float* parts, int nparts, float l2, float* reg_loss_out,
+                                          const float* losses8, const float* mask_loss, const float* reg_loss_in, float* ring,
+                                          int ring_len, void* stream) {
+  DY_REQUIRE(step_counter && nparts >= 0 && (!reg_loss_out || (parts && nparts > 0)), "adam_finish_record: bad args");
+  DY_REQUIRE(losses8 && mask_loss && ring && ring_len > 0, "adam_finish_record: losses8, mask_loss, ring must be given");
+  DY_RECORD_OR_RUN([=](void* s) {
+    return disyolo_adam_finish_record(step_counter, parts, nparts, l2, reg_loss_out, losses8, mask_loss, reg_loss_in, ring, ring_len, s);
+  });
+  hipLaunchKernelGGL(adam_fused_tail_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, step_counter, parts, nparts,
+                     0.5f * l2, reg_loss_out, losses8, mask_loss, reg_loss_in, ring, ring_len);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }

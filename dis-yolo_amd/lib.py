@@ -132,6 +132,7 @@ _SIGS = {
     "disyolo_adam_sweep": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int64, C.c_void_p] + [C.c_float] * 4 +
                            [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "disyolo_adam_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "disyolo_adam_finish_record": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]),
     "disyolo_adam_step_fused": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int64, C.c_void_p] + [C.c_float] * 4 +
                                 [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "disyolo_add_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
@@ -1008,9 +1009,16 @@ def adam_sweep(w, grad, m, v, n, n_decay, lr_dev, b1, b2, eps, l2, step_counter,
                                      _p(step_counter), grad_scale, _p(parts), _stream()), "adam_sweep")
 
 
-def adam_finish(step_counter, parts, nparts, l2, reg_loss_out) -> None:
-    _check(load().disyolo_adam_finish(_p(step_counter), _p(parts), nparts, l2, _p(reg_loss_out), _stream()),
-           "adam_finish")
+def adam_finish(step_counter, parts, nparts, l2, reg_loss_out, record=None) -> None:
+    """record = (losses8, mask_loss, reg_loss_in or None, ring): also file the step's total loss into the ring"""
+    if record is None:
+        _check(load().disyolo_adam_finish(_p(step_counter), _p(parts), nparts, l2, _p(reg_loss_out), _stream()),
+               "adam_finish")
+        return
+    losses8, mask_loss, reg_in, ring = record
+    _need(ring, torch.float32, "ring")
+    _check(load().disyolo_adam_finish_record(_p(step_counter), _p(parts), nparts, l2, _p(reg_loss_out), _p(losses8),
+                                             _p(mask_loss), _p(reg_in), _p(ring), ring.numel(), _stream()), "adam_finish_record")
 
 
 def add_bf16(src, dst, accumulate: bool) -> None:

@@ -183,6 +183,7 @@ class YOLONet(object):
         # next replay waits, tensor by tensor, for the side-lane work that still reads it (cmdlist slots)
         self._overlap = False
         self._overlap_rec = False      # while such a step is being recorded
+        self._dp_pending = []          # data parallel, exchange in the list: slices exchanged and not yet swept
         self._tail_open = False        # a replay's side lane may still be running: join before anything but the next replay
         self._progs = None      # [parity] -> (list, marks, bwd_end) of the pipelined step
         # conv1 + conv2 as ONE launch wherever both run in inference mode (the locked backbone of stage 1, every inference
@@ -450,6 +451,8 @@ class YOLONet(object):
             self.losses = torch.zeros(8, dtype=F32, device=dev)
             self.mask_loss = torch.zeros(1, dtype=F32, device=dev)
             self.reg_loss = torch.zeros(1, dtype=F32, device=dev)
+            # total loss of the last LOSS_RING steps, filed by the optimizer's finish (step_losses())
+            self.loss_ring = torch.zeros(self.LOSS_RING, dtype=F32, device=dev)
             # temp for the data gradient of the fused upsample+concat layers (full-res, C1 ch)
             tmax = 0
             for l in self.layers:
@@ -1105,6 +1108,8 @@ class YOLONet(object):
                 self._plan_opt_chunks()
             self._opt_swept = set()
             self._opt_done = [set() for _ in self.opt_chunks]
+            self._dp_pending = []        # (slice, mark of its collective on the exchange lane, layer position): exchanged, not yet swept
+            self._dp_sweep_delay = int(os.environ.get("DISYOLO_DP_SWEEP_DELAY", "2"))
         for l in visit:
             pos = order.index(l) if not l.lock else -1
             if l.idx == 82 and getattr(self, "_mask_loss_pending", False):
@@ -1223,24 +1228,30 @@ class YOLONet(object):
                 self._opt_done[ci].add(l.idx)
                 if self._opt_done[ci] == self.opt_chunks[ci]["members"]:
                     if inl:
-                        # data parallel: the slice's gradients are summed over the ranks first.  Collective + sweep +
-                        # re-pack on the exchange lane, behind the side lane's weight gradients of the slice and the
-                        # main lane up to here: the side lane goes on with the next layers' weight gradients meanwhile
+                        # data parallel: the slice's gradients are summed over the ranks first -- the collective goes to the
+                        # exchange lane (behind the side lane's weight gradients of the slice; the side lane itself goes
+                        # on with the next layers' weight gradients), and the sweep of a slice is issued a few layers
+                        # later (DISYOLO_DP_SWEEP_DELAY), on the side lane like the single-GPU step's: its collective has
+                        # had those layers' time on the links before the side lane sits behind it
                         L.lane_wait(L.lane_mark(1), L.COMM_LANE)
-                        L.lane_wait(L.lane_mark(0), L.COMM_LANE)
                         L.set_lane(L.COMM_LANE)
-                        self._sweep_chunk(ci, 1.0 / self.dp.world_size)
+                        ch = self.opt_chunks[ci]
+                        self.dp.exchange_inlist(ci, ch["off"], ch["cnt"])
+                        self._dp_pending.append((ci, L.lane_mark(L.COMM_LANE), pos))
+                        L.set_lane(0)
                     else:
                         L.lane_wait(L.lane_mark(0), 1)
                         L.set_lane(1)
                         self._sweep_chunk(ci, 1.0)
-                    L.set_lane(0)
+                        L.set_lane(0)
+            if overlap_opt and inl:
+                # the sweep of a slice follows its collective DISYOLO_DP_SWEEP_DELAY layers later, on the side lane
+                while self._dp_pending and pos - self._dp_pending[0][2] >= self._dp_sweep_delay:
+                    self._dp_sweep_oldest(1)
             if on_layer_done is not None:
                 on_layer_done(l)
         if not self._overlap_rec:
             L.lane_sync(1, 0)
-            if inl:
-                L.lane_sync(L.COMM_LANE, 0)
 
     def _apply_tiles(self) -> None:
         """rebuild everything that depends on a tile choice: batch-norm partial-sum buffers
@@ -1352,14 +1363,25 @@ class YOLONet(object):
         """Adam over slice ci + the re-pack of its layers"""
         ch = self.opt_chunks[ci]
         o, c = ch["off"], ch["cnt"]
-        if self.dp is not None and self.dp.inlist:
-            self.dp.exchange_inlist(ci, o, c)
         L.adam_sweep(self.arena[o:o + c], self.grad_arena[o:o + c], self.adam_m[o:o + c], self.adam_v[o:o + c], c, c,
                      self.lr_dev, cfg.ADAM_BETA1, cfg.ADAM_BETA2, cfg.ADAM_EPSILON, self.l2, self.step_dev, grad_scale,
                      self._opt_parts[ch["parts_off"]:ch["parts_off"] + ch["nparts"]])
         if ch["pack"] is not None:
             ch["pack"].run()
         self._opt_swept.add(ci)
+
+    def _dp_sweep_oldest(self, lane: int) -> None:
+        """data parallel, exchange in the list: the optimizer sweep (+ re-pack) of the slice whose collective was issued
+        first, on ``lane`` behind that collective and behind the main lane up to here (the re-pack rewrites operands the
+        main lane's data-gradient convs read)"""
+        ci, mk = self._dp_pending.pop(0)[:2]
+        L.lane_wait(mk, lane)
+        if lane != 0:
+            L.lane_wait(L.lane_mark(0), lane)
+        prev = L.CURRENT_LANE
+        L.set_lane(lane)
+        self._sweep_chunk(ci, 1.0 / self.dp.world_size)
+        L.set_lane(prev)
 
     def optimizer_step(self, grad_scale: float = 1.0) -> None:
         """tf.train.AdamOptimizer(1e-4).minimize (train_yolo3_mask.py:55) over the arena; the
@@ -1370,21 +1392,57 @@ class YOLONet(object):
         if self.n_params:
             if self.opt_chunks is None:
                 self._plan_opt_chunks()
+            nt = self.n_params - self.n_decay       # batch-norm gamma / beta: not regularised
+            if self.dp is not None and self.dp.inlist:
+                # the collectives of everything not exchanged yet (the slices that became final last, gamma / beta) on the
+                # exchange lane, behind what this lane has seen; the sweeps follow on this lane, oldest collective first
+                cur = L.CURRENT_LANE
+                pend = {p[0] for p in self._dp_pending}
+                L.lane_wait(L.lane_mark(cur), L.COMM_LANE)
+                L.set_lane(L.COMM_LANE)
+                for ci in range(len(self.opt_chunks)):
+                    if ci not in self._opt_swept and ci not in pend:
+                        ch = self.opt_chunks[ci]
+                        self.dp.exchange_inlist(ci, ch["off"], ch["cnt"])
+                        self._dp_pending.append((ci, L.lane_mark(L.COMM_LANE), 0))
+                if nt > 0:
+                    self.dp.exchange_inlist("tail", self.n_decay, nt)
+                tail_mark = L.lane_mark(L.COMM_LANE)
+                L.set_lane(cur)
+                while self._dp_pending:
+                    self._dp_sweep_oldest(cur)
+                L.lane_wait(tail_mark, cur)
             for ci in range(len(self.opt_chunks)):
                 if ci not in self._opt_swept:
                     self._sweep_chunk(ci, grad_scale)
-            nt = self.n_params - self.n_decay       # batch-norm gamma / beta: not regularised
             if nt > 0:
                 o = self.n_decay
-                if self.dp is not None and self.dp.inlist:
-                    self.dp.exchange_inlist("tail", o, nt)
                 L.adam_sweep(self.arena[o:], self.grad_arena[o:], self.adam_m[o:], self.adam_v[o:], nt, 0, self.lr_dev,
                              cfg.ADAM_BETA1, cfg.ADAM_BETA2, cfg.ADAM_EPSILON, self.l2, self.step_dev, grad_scale, None)
             L.adam_finish(self.step_dev, self._opt_parts if self.n_decay else None, self._opt_nparts if self.n_decay else 0,
-                          self.l2, self.reg_loss if self.n_decay else None)
+                          self.l2, self.reg_loss if self.n_decay else None,
+                          record=(self.losses, self.mask_loss, None if self.n_decay else self.reg_loss, self.loss_ring))
             self._opt_swept = set()
             self._opt_done = [set() for _ in self.opt_chunks]
+            self._dp_pending = []
             self._reg_fresh = True
+
+    LOSS_RING = 1024
+
+    def step_losses(self, first: int, count: int) -> np.ndarray:
+        """total_loss of the optimizer steps first .. first+count-1 (0-based, counted like ``step_count``) as the
+        finish filed them on the device -- bit for bit what total_loss() returned after each of those steps.  Lets a
+        training loop accumulate the loss of every step, as the reference does with the value sess.run hands back
+        (train_yolo3_mask.py:216-218), while fetching from the device once per ``count`` <= LOSS_RING steps instead of
+        once per step (each fetch joins an overlapped tail)."""
+        if count < 0 or count > self.LOSS_RING:
+            raise L.DisyoloError("step_losses: at most %d steps are kept" % self.LOSS_RING)
+        done = self.step_count         # (joins)
+        if first < 0 or first + count > done or done - first > self.LOSS_RING:
+            raise L.DisyoloError("step_losses: steps %d..%d are not in the ring (steps done: %d, ring %d)"
+                                 % (first, first + count - 1, done, self.LOSS_RING))
+        ring = self.loss_ring.cpu().numpy()
+        return np.asarray([ring[(first + i) % self.LOSS_RING] for i in range(count)], np.float32)
 
     def repack(self) -> None:
         """bf16 MFMA operands of every trainable layer from the f32 masters"""
@@ -1541,16 +1599,10 @@ class YOLONet(object):
             if self._overlap_rec:
                 # what is left of the optimizer (the slices that became final last, gamma / beta, the finish) stays on the side
                 # lane behind the last weight gradients; it needs the main lane's last batch-norm gradients
-                # (data parallel: on the exchange lane, each sweep behind its slice's collective; the side lane then waits
-                # for the exchange lane, so "the end of the side lane" still means "the step is complete")
-                tl = L.COMM_LANE if inl else 1
-                L.lane_wait(L.lane_mark(0), tl)
-                if inl:
-                    L.lane_wait(L.lane_mark(1), tl)
-                L.set_lane(tl)
+                # (data parallel: the remaining collectives go to the exchange lane, the sweeps wait for them here)
+                L.lane_wait(L.lane_mark(0), 1)
+                L.set_lane(1)
                 self.optimizer_step(1.0 / self.dp.world_size if inl else 1.0)
-                if inl:
-                    L.lane_sync(tl, 1)
                 L.lane_mark_slot(1, self.SLOT_ALL)
                 L.set_lane(0)
             else:

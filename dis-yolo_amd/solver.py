@@ -12,7 +12,12 @@ Differences, all deliberate and switchable:
     (SURVEY F6).  ``lr_schedule="faithful"`` (default) therefore trains at 1e-4 and prints the
     schedule's value like the reference; ``"intended"`` applies it (the optimizer kernel reads the rate
     from device memory, so the recorded step follows it);
-  * summaries go to ``events.jsonl`` in the checkpoint directory (no TensorBoard writer here).
+  * summaries go to ``events.jsonl`` in the checkpoint directory (no TensorBoard writer here);
+  * the loss of every step is accumulated like the reference does (:216-218), but FETCHED in blocks: the optimizer's
+    finish files each step's total loss in a device ring (``YOLONet.step_losses``) and the loop reads it at the summary
+    / checkpoint steps (at the latest every ``YOLONet.LOSS_RING`` steps).  Same values, same order of accumulation; the
+    device is joined once per block instead of once per step, so the recorded step's overlapped tail
+    (``build_program(overlap_tail=True)``: what bench.py times) is what a real run gets too.
 """
 from __future__ import annotations
 
@@ -41,9 +46,10 @@ class Timer:
     def tic(self) -> None:
         self._t0 = time.perf_counter()
 
-    def toc(self) -> float:
+    def toc(self, count: int = 1) -> float:
+        """``count`` intervals ended since tic() (a block of steps timed as one)"""
         self._sum += time.perf_counter() - self._t0
-        self._n += 1
+        self._n += count
         return self.average_time
 
     @property
@@ -149,11 +155,28 @@ class Solver(object):
             net.set_batch(self._feed_peek())
             if getattr(net, "pair", False):
                 net.set_batch(self._pending, 1)      # (placeholder inputs while the two lists are recorded)
-            net.build_program(det_thresh=cfg.OBJ_THRESHOLD)
+            overlap = (net.use_side_lane and not getattr(net, "pair", False) and (net.dp is None or net.dp.inlist))
+            net.build_program(det_thresh=cfg.OBJ_THRESHOLD, overlap_tail=overlap)
         history = []
+        first_pending = net.step_count       # the ring index of the first step whose loss has not been fetched yet
+        n_pending = 0
+        train_timer.tic()
+
+        def fetch():
+            """the losses of the steps run since the last fetch: accumulated one by one, in order, like :218"""
+            nonlocal epoch_loss, first_pending, n_pending
+            if n_pending:
+                for v in net.step_losses(first_pending, n_pending):       # (joins the device)
+                    epoch_loss += float(v)
+                    history.append(float(v))
+                train_timer.toc(n_pending)
+                first_pending += n_pending
+                n_pending = 0
+            train_timer.tic()
+
         for step in range(self.start_iter, self.max_iter + 1):
             shown_lr = scheduled_learning_rate(step)
-            if self.lr_schedule == "intended":
+            if self.lr_schedule == "intended" and shown_lr != self.learning_rate:
                 self.learning_rate = shown_lr
                 net.learning_rate = shown_lr
             load_timer.tic()
@@ -164,12 +187,12 @@ class Solver(object):
             else:
                 feed = self._next_feed()
             load_timer.toc()
-            train_timer.tic()
-            loss = float(net.train_step(feed, det_thresh=cfg.OBJ_THRESHOLD).cpu())
-            train_timer.toc()
+            net.train_step(feed, det_thresh=cfg.OBJ_THRESHOLD, want_loss=False)
+            n_pending += 1
             self.global_step += 1
-            epoch_loss += loss
-            history.append(loss)
+            if (step % self.summary_iter == 0 or step % self.save_iter == 0 or step == self.max_iter
+                    or n_pending == net.LOSS_RING):
+                fetch()
             if step % self.summary_iter == 0:
                 summ = net.summaries()
                 summ["step"] = step
@@ -191,6 +214,7 @@ class Solver(object):
                         thresh_out["mAP"][2], train_timer.average_time, load_timer.average_time,
                         train_timer.remain(step, self.max_iter)))
                     epoch_loss = 0.0
+                    train_timer.tic()
             if step % self.save_iter == 0:
                 self.log("{} Saving checkpoint file to: {}".format(datetime.datetime.now().strftime("%m/%d %H:%M:%S"),
                                                                    self.ckpt_dir))

@@ -423,6 +423,14 @@ int disyolo_adam_sweep(float* w, const float* grad, float* m, float* v, int64_t 
                        const int64_t* step_counter, float grad_scale, float* parts, void* stream);
 int disyolo_adam_finish(int64_t* step_counter, const float* parts, int nparts, float l2,
                         float* reg_loss_out, void* stream);
+/* the finish that also files the step's total loss (get_total_loss, yolo/yolo3_net_pos.py:61: the four YOLO terms
+ * [losses8[7]] + the mask term + the l2 term) into ring[t % ring_len], t = the counter before its increment.  The
+ * reference fetches total_loss with every sess.run (train_yolo3_mask.py:216) and only accumulates it (:218); a host that
+ * reads the ring every ring_len steps or less gets the same values without joining the device once per step.
+ * reg_loss_in: the l2 term when this finish sums none (reg_loss_out NULL); NULL = 0. */
+int disyolo_adam_finish_record(int64_t* step_counter, const float* parts, int nparts, float l2, float* reg_loss_out,
+                               const float* losses8, const float* mask_loss, const float* reg_loss_in, float* ring,
+                               int ring_len, void* stream);
 /* 0.5*l2*sum(w[0:n]^2) -> out f32[1] (only needed when the loss value is logged) */
 size_t disyolo_l2_workspace(int64_t n);
 int disyolo_l2_loss(const float* w, int64_t n, float l2, float* out, void* workspace,
