@@ -1,5 +1,6 @@
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include <utility>
 #include <vector>
 #include "common.h"
@@ -80,31 +81,142 @@ extern "C" uint32_t disyolo_crc32c(const void* data, size_t n, uint32_t crc) {
 }
 
 bool dy_recording() { return g_rec != nullptr; }
+static bool ensure_lane(CmdList* c, int i);
+static void use_lane(CmdList* c, int lane) {
+  c->uses[lane] = true;
+  (void)ensure_lane(c, lane);       // (without a device the list records and cmdlist_run refuses)
+}
 int dy_record(std::function<int(void*)> fn) {
   g_rec->cmds.push_back(Cmd{std::move(fn), 0, g_lane, 0, 0, nullptr});
-  g_rec->uses[g_lane] = true;
+  use_lane(g_rec, g_lane);
+  return DISYOLO_OK;
+}
+
+// Side lanes are streams of ONE process-wide pool, created on first use (or ahead of time: disyolo_lanes_reserve) and
+// shared by every list.  Round 5 found the step's speed hostage to how the runtime maps streams to hardware queues: a
+// third, never used side stream per list made the hipGraph-captured B = 32 inference 23 % slower (6.09 k -> 4.66 k img/s
+// same box); with a process group initialised first (torch's stream pool takes the hardware queues: later streams SHARE
+// one, least-used first) a lane created afterwards can land on the caller's stream's queue and the step runs 2.5x
+// slower.  So: no stream exists that no list uses, and a process that will initialise RCCL reserves its lanes BEFORE.
+// lane 1 (weight gradients, detection filter, mask loss) runs beside the critical chain on the caller's stream: lowest
+// stream priority, so the chain's kernels get the CU slots first when both have blocks pending (+1.5-2 % measured).
+// DISYOLO_LANE1_LOW=0 keeps it at normal priority (the cut-list data-parallel step does: its RCCL all-reduces are issued on
+// this lane).  lane 2 carries work that must only fill the other lanes' bubbles (the next step's backbone); lane 3 the
+// data-parallel step's RCCL collectives (normal priority).
+static hipStream_t g_pool[NLANES] = {};
+#ifndef DY_HOST_ONLY
+__global__ void lane_probe_spin_kernel(long long ticks) {     // wall_clock64: 100 MHz
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {
+  }
+}
+static double host_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// Two measurements of a stream pair (tools/micro/queue_probe.hip, profiles/r05_hw_queues.txt).  Streams map to hardware
+// queues, queues to the command processor's pipes, and three kinds of neighbour exist for a given stream: one that runs
+// beside it (two 100-us kernels: 110 us; a chain of 20 x 10-us kernels on `a` with `b` parked on an event behind it: 1.0x
+// the chain alone), one that SHARES its queue (kernels serialise: 200 us) and one that runs beside it but stalls it while
+// blocked on an event (the chain takes 1.8-2x: the pathological case -- a side lane spends most of its life parked on
+// the main lane's events).  Which stream index is which changes with GPU_MAX_HW_QUEUES, priorities and how many streams
+// the process already has, so the lanes are CHOSEN by measurement instead of by creation order.
+static bool lane_pair_ok(hipStream_t a, hipStream_t b, double chain_alone_us) {
+  hipEvent_t ev;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return true;
+  (void)hipDeviceSynchronize();
+  double t0 = host_now();
+  hipLaunchKernelGGL(lane_probe_spin_kernel, dim3(1), dim3(64), 0, a, 100 * 100LL);
+  hipLaunchKernelGGL(lane_probe_spin_kernel, dim3(1), dim3(64), 0, b, 100 * 100LL);
+  (void)hipDeviceSynchronize();
+  const double both = (host_now() - t0) * 1e6;
+  t0 = host_now();
+  for (int r = 0; r < 20; ++r) hipLaunchKernelGGL(lane_probe_spin_kernel, dim3(1), dim3(64), 0, a, 10 * 100LL);
+  (void)hipEventRecord(ev, a);
+  (void)hipStreamWaitEvent(b, ev, 0);
+  hipLaunchKernelGGL(lane_probe_spin_kernel, dim3(1), dim3(64), 0, b, 10 * 100LL);
+  (void)hipDeviceSynchronize();
+  const double chain = (host_now() - t0) * 1e6;
+  (void)hipEventDestroy(ev);
+  static const bool verbose = getenv("DISYOLO_LANE_PROBE") && getenv("DISYOLO_LANE_PROBE")[0] == '2';
+  if (verbose) fprintf(stderr, "[lane probe] %p beside %p: two 100-us kernels %.0f us, chain %.0f us (alone %.0f)\n", (void*)b, (void*)a, both, chain, chain_alone_us);
+  return both < 170.0 && chain < 1.45 * chain_alone_us + 15.0;
+}
+static double lane_chain_alone(hipStream_t a) {
+  double best = 1e30;
+  for (int k = 0; k < 2; ++k) {
+    (void)hipDeviceSynchronize();
+    const double t0 = host_now();
+    for (int r = 0; r < 21; ++r) hipLaunchKernelGGL(lane_probe_spin_kernel, dim3(1), dim3(64), 0, a, 10 * 100LL);
+    (void)hipDeviceSynchronize();
+    const double t = (host_now() - t0) * 1e6;
+    if (t < best) best = t;
+  }
+  return best;
+}
+#endif
+static bool pool_lane(int i) {
+  if (i <= 0 || i >= NLANES) return false;
+  if (g_pool[i]) return true;
+  int least = 0, greatest = 0;
+  const char* l1 = getenv("DISYOLO_LANE1_LOW");
+  const bool lane1_low = !(l1 && l1[0] == '0');
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;   // no device (CPU-only build check)
+  const bool low = (i == 2 && getenv("DISYOLO_LANE2_LOW")) || (i == 1 && lane1_low);
+  const int prio = low ? least : 0;
+#ifndef DY_HOST_ONLY
+  const char* pe = getenv("DISYOLO_LANE_PROBE");
+  if (!(pe && pe[0] == '0')) {
+    // candidates in creation order until one runs beside the caller's (null) stream and beside the lanes that exist, in both
+    // roles; the rejected ones are released afterwards.  DISYOLO_LANE_PROBE=0: the first stream, unmeasured; =2: verbose
+    hipStream_t rejected[16];
+    int nrej = 0;
+    hipStream_t pick = nullptr;
+    const double alone0 = lane_chain_alone(nullptr);
+    while (nrej < 16) {
+      hipStream_t c = nullptr;
+      if (hipStreamCreateWithPriority(&c, hipStreamNonBlocking, prio) != hipSuccess) break;
+      bool ok = lane_pair_ok(nullptr, c, alone0) && lane_pair_ok(c, nullptr, lane_chain_alone(c));
+      for (int j = 1; j < NLANES && ok; ++j)
+        if (g_pool[j]) ok = lane_pair_ok(g_pool[j], c, lane_chain_alone(g_pool[j])) && lane_pair_ok(c, g_pool[j], lane_chain_alone(c));
+      if (ok) {
+        pick = c;
+        break;
+      }
+      rejected[nrej++] = c;
+    }
+    if (!pick && nrej > 0) pick = rejected[--nrej];      // nothing passed: the last candidate (the step still runs)
+    for (int k = 0; k < nrej; ++k) (void)hipStreamDestroy(rejected[k]);
+    (void)hipGetLastError();
+    if (pick) {
+      g_pool[i] = pick;
+      return true;
+    }
+    return false;
+  }
+#endif
+  if (hipStreamCreateWithPriority(&g_pool[i], hipStreamNonBlocking, prio) != hipSuccess) {
+    g_pool[i] = nullptr;
+    return false;
+  }
+  return true;
+}
+static bool ensure_lane(CmdList* c, int i) {
+  if (i <= 0 || i >= NLANES) return i == 0;
+  if (c->side[i]) return true;
+  if (!pool_lane(i)) return false;
+  if (hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess) return false;
+  c->side[i] = g_pool[i];
+  return true;
+}
+// create the side streams of the lanes in `mask` (bit i = lane i) now, on the current device: call before anything else
+// that creates many streams (torch.distributed's NCCL backend) so the lanes get hardware queues of their own
+extern "C" int disyolo_lanes_reserve(int mask) {
+  for (int i = 1; i < NLANES; ++i)
+    if ((mask >> i) & 1) DY_REQUIRE(pool_lane(i), "lanes_reserve: cannot create the stream of lane %d", i);
   return DISYOLO_OK;
 }
 
 extern "C" void* disyolo_cmdlist_create(void) {
   CmdList* c = new CmdList();
-  bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
-  // lane 1 (weight gradients, detection filter, mask loss) runs beside the critical chain on the
-  // caller's stream: lowest stream priority, so the chain's kernels get the CU slots first when
-  // both have blocks pending (+1.5-2 % measured).  DISYOLO_LANE1_LOW=0 keeps it at normal priority
-  // (the data-parallel step does: its RCCL all-reduces are issued on this lane).
-  // lane 2 carries work that must only fill the other lanes' bubbles (the next step's backbone)
-  // lane 3 carries the data-parallel step's RCCL collectives and the optimizer sweeps behind them (normal priority)
-  int least = 0, greatest = 0;
-  const char* l1 = getenv("DISYOLO_LANE1_LOW");
-  const bool lane1_low = !(l1 && l1[0] == '0');
-  if (ok) ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
-  for (int i = 1; i < NLANES && ok; ++i)
-    ok = hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking,
-                                     ((i == 2 && getenv("DISYOLO_LANE2_LOW")) || (i == 1 && lane1_low)) ? least : 0) == hipSuccess &&
-         hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
-  if (!ok)  // no device (CPU-only build check): lists can still be recorded, not run
-    for (int i = 1; i < NLANES; ++i) c->side[i] = nullptr;
+  (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);   // (fails without a device: lists can still be recorded, not run)
   return c;
 }
 extern "C" void disyolo_cmdlist_destroy(void* l) {
@@ -115,10 +227,8 @@ extern "C" void disyolo_cmdlist_destroy(void* l) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   for (int i = 0; i < NSLOTS; ++i)
     if (c->slot_ev[i]) (void)hipEventDestroy(c->slot_ev[i]);
-  for (int i = 1; i < NLANES; ++i) {
-    if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
-    if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
-  }
+  for (int i = 1; i < NLANES; ++i)
+    if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);      // (the streams belong to the process-wide pool)
   delete c;
 }
 extern "C" int disyolo_cmdlist_begin(void* l) {
@@ -144,7 +254,8 @@ extern "C" int disyolo_cmdlist_sync(int from, int to) {
     return DISYOLO_E_HIP;
   }
   g_rec->cmds.push_back(Cmd{nullptr, 1, 0, from, to, ev});
-  g_rec->uses[from] = g_rec->uses[to] = true;
+  use_lane(g_rec, from);
+  use_lane(g_rec, to);
   return DISYOLO_OK;
 }
 // mark: remember this point of lane `lane`; wait: lane `lane` waits for a mark made EARLIER in the list -- unlike
@@ -159,7 +270,7 @@ extern "C" int disyolo_cmdlist_mark(int lane) {
     return DISYOLO_E_HIP;
   }
   g_rec->cmds.push_back(Cmd{nullptr, 2, 0, lane, 0, ev});
-  g_rec->uses[lane] = true;
+  use_lane(g_rec, lane);
   return (int)g_rec->cmds.size() - 1;
 }
 extern "C" int disyolo_cmdlist_wait(int mark, int lane) {
@@ -167,7 +278,7 @@ extern "C" int disyolo_cmdlist_wait(int mark, int lane) {
   DY_REQUIRE(lane >= 0 && lane < NLANES, "cmdlist_wait: bad lane");
   DY_REQUIRE(mark >= 0 && mark < (int)g_rec->cmds.size() && g_rec->cmds[mark].kind == 2, "cmdlist_wait: %d is not a mark of this list", mark);
   g_rec->cmds.push_back(Cmd{nullptr, 3, 0, mark, lane, nullptr});
-  g_rec->uses[lane] = true;
+  use_lane(g_rec, lane);
   return DISYOLO_OK;
 }
 // Named marks that outlive a replay.  mark_slot: remember this point of `lane` under `slot`; wait_slot: `lane` waits for
@@ -183,14 +294,14 @@ extern "C" int disyolo_cmdlist_mark_slot(int lane, int slot) {
     return DISYOLO_E_HIP;
   }
   g_rec->cmds.push_back(Cmd{nullptr, 4, 0, lane, slot, nullptr});
-  g_rec->uses[lane] = true;
+  use_lane(g_rec, lane);
   return DISYOLO_OK;
 }
 extern "C" int disyolo_cmdlist_wait_slot(int slot, int lane) {
   DY_REQUIRE(lane >= 0 && lane < NLANES && slot >= 0 && slot < NSLOTS, "cmdlist_wait_slot: lane 0..%d, slot 0..%d", NLANES - 1, NSLOTS - 1);
   if (!g_rec) return DISYOLO_OK;
   g_rec->cmds.push_back(Cmd{nullptr, 5, 0, slot, lane, nullptr});
-  g_rec->uses[lane] = true;
+  use_lane(g_rec, lane);
   return DISYOLO_OK;
 }
 extern "C" int disyolo_cmdlist_end(void) {
@@ -199,10 +310,11 @@ extern "C" int disyolo_cmdlist_end(void) {
   return DISYOLO_OK;
 }
 extern "C" int disyolo_cmdlist_size(void* l) { return l ? (int)((CmdList*)l)->cmds.size() : DISYOLO_E_ARG; }
-extern "C" void* disyolo_cmdlist_side_stream(void* l) { return l ? (void*)((CmdList*)l)->side[1] : nullptr; }
 extern "C" void* disyolo_cmdlist_lane_stream(void* l, int lane) {
-  return (l && lane >= 1 && lane < NLANES) ? (void*)((CmdList*)l)->side[lane] : nullptr;
+  if (!l || lane < 1 || lane >= NLANES || !ensure_lane((CmdList*)l, lane)) return nullptr;
+  return (void*)((CmdList*)l)->side[lane];
 }
+extern "C" void* disyolo_cmdlist_side_stream(void* l) { return disyolo_cmdlist_lane_stream(l, 1); }
 
 extern "C" int disyolo_cmdlist_run(void* l, int first, int last, void* stream) {
   return disyolo_cmdlist_run_ex(l, first, last, stream, 3);

@@ -151,6 +151,7 @@ _SIGS = {
     "disyolo_cmdlist_run_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "disyolo_cmdlist_side_stream": (C.c_void_p, [C.c_void_p]),
     "disyolo_cmdlist_lane_stream": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "disyolo_lanes_reserve": (C.c_int, [C.c_int]),
     "disyolo_comm_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "disyolo_comm_unique_id": (C.c_int, [C.c_void_p]),
     "disyolo_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -1034,6 +1035,16 @@ def l2_loss(w, n, l2, out, ws: Workspace) -> None:
 # ---- gradient exchange as commands of the step (csrc/comm.hip) -------------------------------------------------
 COMM_LANE = 3        # the list's lane that carries the collectives and the optimizer sweeps behind them
 _DT_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float64: 2}
+
+
+def reserve_lanes(lanes=(1, COMM_LANE)) -> None:
+    """create the side streams of these lanes now (current device).  A data-parallel process calls this BEFORE
+    torch.distributed.init_process_group("nccl"): streams created after torch's stream pool exists share hardware
+    queues with it, and a lane that shares the caller's stream's queue serialises the step (2.5x, round 5)."""
+    mask = 0
+    for i in lanes:
+        mask |= 1 << int(i)
+    _check(load().disyolo_lanes_reserve(mask), "lanes_reserve")
 
 
 def rccl_path() -> Optional[str]:

@@ -940,11 +940,21 @@ class YOLONet(object):
         if self.masks is None:
             self.masks = torch.zeros(self.B, cfg.MAX_DETECTION, Sm, Sm, dtype=F32, device=self.device)
         prog = L.CmdList()
-        with prog:
-            self._forward_layers(False)
-            self._detect(det_thresh)
-            L.psroi_assemble(self.by_idx[82].act, self.detections, self.B, cfg.MAX_DETECTION, Sm, self.k, self.masks,
-                             self.keep)
+        # a hipGraph is captured from ONE lane: the graph executor runs a captured side lane on a stream of its own choosing,
+        # and whether that stream's hardware queue runs beside the launch stream's or stalls it is out of the caller's hands
+        # (round 5, same box: 5.25 ms per B = 32 batch with one mapping, 7.1 ms with another; one lane: 5.42 ms always.  The
+        # list replayed directly keeps its measured side lane: 5.38 ms)
+        side_lane = self.use_side_lane
+        if graph:
+            self.use_side_lane = False
+        try:
+            with prog:
+                self._forward_layers(False)
+                self._detect(det_thresh)
+                L.psroi_assemble(self.by_idx[82].act, self.detections, self.B, cfg.MAX_DETECTION, Sm, self.k, self.masks,
+                                 self.keep)
+        finally:
+            self.use_side_lane = side_lane
         self.ws.frozen = True
         self._infer_prog = prog
         self._infer_graph = None

@@ -502,6 +502,10 @@ int disyolo_cmdlist_run(void* list, int first, int last, void* stream);
 int disyolo_cmdlist_run_ex(void* list, int first, int last, void* stream, int flags);
 void* disyolo_cmdlist_side_stream(void* list);
 void* disyolo_cmdlist_lane_stream(void* list, int lane);   /* lane 1..3 (side_stream = lane 1) */
+/* the side lanes are streams of one process-wide pool, created when a list first uses them; lanes_reserve(mask) (bit i =
+ * lane i) creates them NOW on the current device -- before torch.distributed's NCCL backend (whose stream pool takes
+ * the hardware queues: a lane created afterwards may share the caller's stream's queue, 2.5x the step time) */
+int disyolo_lanes_reserve(int mask);
 
 /* ---- data-parallel gradient exchange as COMMANDS of the step (csrc/comm.hip) ----
  * The reference trains on one GPU (yolo/config.py:18; the op being distributed is train_yolo3_mask.py:55-56,
