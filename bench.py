@@ -499,7 +499,7 @@ def main():
     n_trained = [0]
 
     feed_sets = None
-    if args.feed == "per-step":
+    if args.feed != "resident":
         if args.pair:
             raise SystemExit("--feed per-step is not wired for --pair")
         feed_sets = []
@@ -639,6 +639,7 @@ def main():
         out["bound_model"] = {"t_bound_ms": round(tb * 1e3, 3), "achieved_vs_bound": round(tb * 1e3 / ms, 4),
                               "definition": "sum over kernels of max(FLOP/2.5 PF, algorithmic bytes/8 TB/s): convs "
                                             "fwd/dgrad/wgrad, BN passes, Adam (SURVEY.md 8d)"}
+        kernels = None
         if timer is not None:
             summ = timer.summary()
             kernels = {}
@@ -693,7 +694,7 @@ def main():
             out["secondary"] = secondary_measurements(args, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.stage, S)
-        if timer is not None:
+        if kernels is not None:
             # last, and only the heaviest instances: a log tail that is cut still carries secondary / cpu_baseline
             top = sorted(kernels, key=lambda k: -kernels[k]["ms_per_step"])[:12]
             out["kernels"] = {k: kernels[k] for k in top}

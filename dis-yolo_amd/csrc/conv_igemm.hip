@@ -1716,7 +1716,11 @@ struct TileCfg {
 const TileCfg kTiles[] = {
     {1, 128, 128}, {2, 128, 64}, {3, 64, 128}, {4, 128, 32}, {5, 128, 16}, {6, 64, 64}, {7, 256, 64}, {8, 256, 128},
     {9, 64, 128}, {10, 96, 128}, {11, 96, 128}, {12, 192, 128}, {13, 64, 128}, {14, 96, 128}, {15, 192, 128},
+    // round 5: two-wave tiles for the deep 1x1 layers whose 64x64 grid is barely one block per CU (18^2: 328 blocks)
+    {26, 32, 64}, {27, 64, 32}, {28, 32, 128},
 };
+// ids 1..15 and 26.. are GEMM tiles of conv_igemm_kernel; 16..25 the patch / streaming / flat-frame kernels
+inline bool is_gemm_tile(int id) { return id < 16 || id >= 26; }
 
 template <int BM, int BN, int WM, int WN, int BK, int ST, int KS, int KG = 1>
 int launch_ks(const ConvParams& p, hipStream_t s) {
@@ -1801,6 +1805,9 @@ int dispatch(int id, bool bk64, int variant, const ConvParams& p, hipStream_t s)
     DY_TILE(10, 96, 128, 2, 2, 2, 3, 4, 3)  // 48x64 wave tiles: fewer bytes staged per FLOP than 64x128
     DY_TILE(11, 96, 128, 2, 2, 4, 5, 6, 4)  // the same, deep pipeline (one block per CU)
     DY_TILE(12, 192, 128, 4, 2, 2, 3, 3, 4) // 8 waves of 48x64
+    DY_TILE(26, 32, 64, 1, 2, 3, 4, 4, 6)
+    DY_TILE(27, 64, 32, 2, 1, 3, 4, 4, 6)
+    DY_TILE(28, 32, 128, 1, 2, 3, 4, 4, 6)
     default: disyolo_set_error("conv: unknown tile id %d", id); return DISYOLO_E_ARG;
   }
 #endif
@@ -1889,7 +1896,7 @@ static int resolve_sel(const disyolo_conv_desc* d, int M, Patch* pt) {
       if (stream1x1_ok(d)) return sel;
     } else if (id == 20) {
       if (stream_ok(d, pt)) return sel;
-    } else if (id >= 16) {
+    } else if (!is_gemm_tile(id)) {
       if (halo_ok(d, id, pt)) return sel;
     } else {
       return sel;
@@ -1915,7 +1922,7 @@ extern "C" int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d) {
     return flat_ok(d, id, &g) ? g.tilesM : DISYOLO_E_ARG;
   }
   if (id == 21) return stream1x1_blocks(M);
-  if (id >= 16) return d->B * (d->H / pt.ph) * (d->W / pt.pw);
+  if (!is_gemm_tile(id)) return d->B * (d->H / pt.ph) * (d->W / pt.pw);
   const int bm = tile_bm(id);
   if (bm == 0) return DISYOLO_E_ARG;
   return ceil_div(M, bm);
@@ -1923,6 +1930,10 @@ extern "C" int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d) {
 
 // stages per (tile id, BK, variant): keep in sync with DY_TILE in dispatch()
 static int tile_stages(int id, bool bk64, int variant) {
+  if (id >= 26) {
+    static const int two_wave[4] = {3, 4, 4, 6};
+    return two_wave[(bk64 ? 0 : 2) + (variant ? 1 : 0)];
+  }
   static const int tab[16][4] = {{0, 0, 0, 0}, {2, 3, 3, 4}, {3, 2, 4, 3}, {2, 3, 4, 3}, {3, 2, 4, 3},
                                  {3, 2, 4, 3}, {3, 2, 4, 3}, {3, 2, 4, 3}, {2, 3, 3, 4}, {6, 4, 6, 4},
                                  {2, 3, 4, 3}, {4, 5, 6, 4}, {2, 3, 3, 4},
@@ -1950,7 +1961,7 @@ extern "C" int disyolo_conv2d_tile(const disyolo_conv_desc* d, int* bm, int* bn,
     if (stages) *stages = 1;
     return 21;
   }
-  if ((sel & 0xff) >= 16) {
+  if (!is_gemm_tile(sel & 0xff)) {
     if (bm) *bm = pt.ph * pt.pw;
     if (bn) *bn = halo_bn(sel & 0xff);
     if (bk) *bk = 32;

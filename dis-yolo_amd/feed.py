@@ -80,3 +80,4 @@ class HostFeeder:
         if det_thresh is None:
             return self.net.train_step(None, want_loss=want_loss)
         return self.net.train_step(None, det_thresh=det_thresh, want_loss=want_loss)
+

@@ -362,6 +362,8 @@ def conv_shape_key(d: ConvDesc):
 # shape key -> tile code, filled by ConvTuner (YOLONet.autotune); consulted by make_conv_desc
 TUNED: dict = {}
 TUNE_CANDIDATES = (3, 0x203, 6, 0x206, 2, 0x202, 0x204, 10, 12, 0x20c, 0x10c, 0x108, 0x20d, 16, 17, 18, 19, 20, 21, 24, 25)
+# (tiles 26 / 27 / 28 -- two-wave 32x64, 64x32, 32x128 GEMM tiles, round 5 -- cover every shape and won nowhere in the step:
+# profiles/r05_two_wave_tiles.txt; pass them explicitly to try them)
 
 
 class ConvTuner:

@@ -332,7 +332,7 @@ def test_sync_bn_on_one_rank_is_the_plain_step(dev, one_rank_rccl, inlist):
 def test_bf16_gradient_storage_along_the_residual_trunk(dev):
     """Stage 2, 192x192, B=2: weight gradients of conv1-10 (the far end of 23 residual blocks whose
     trunk gradient is rounded to bf16 once per block) and of conv43-52 (the near end) against the oracle
-    differentiated in f32 at the HIP path's own activations.  Records the numbers (DESIGN.md section 4)."""
+    differentiated in f32 at the HIP path's own activations.  Records the numbers (DESIGN.md section 6)."""
     B, S = 2, 192
     net = YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=2, seed=2)
     seeded_heads(net, 41, gain=6.0, bias_std=0.5)

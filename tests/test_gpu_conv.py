@@ -94,6 +94,13 @@ CASES = [
     (1, 72, 72, 64, 64, 3, 1, 25),         # ... P = 73: nine DMA pieces per wave
     (1, 20, 20, 32, 64, 3, 2, 24),         # stride 2 / 32 input channels: not covered, falls back
     (2, 18, 18, 64, 72, 3, 1, 24),         # Cout not a multiple of 64: falls back
+    (1, 16, 16, 1024, 512, 1, 1, 26),      # two-wave 32x64 tile on a deep 1x1 layer (16 K slices)
+    (2, 18, 18, 512, 256, 1, 1, 0x21a),    # ... alternative pipeline depth, ragged last M tile (648 = 20 x 32 + 8)
+    (2, 18, 18, 96, 72, 3, 1, 26),         # ... 3x3, BK = 32, ragged channel tile
+    (1, 16, 16, 1024, 512, 1, 1, 27),      # 64x32 tile (two waves along M)
+    (2, 17, 19, 32, 40, 3, 2, 27),         # ... stride 2, odd sizes, ragged M and N
+    (2, 18, 18, 512, 256, 1, 1, 28),       # 32x128 tile (32x64 wave tiles)
+    (2, 12, 12, 128, 64, 1, 1, 0x21c),     # ... nk = 2, fewer slices than stages; N smaller than the tile
 ]
 
 

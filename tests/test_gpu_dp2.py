@@ -229,7 +229,7 @@ def test_sync_bn_two_ranks_train_like_one_process_with_the_global_batch(dev, tmp
     asserted tightly: the statistics of the FIRST trainable layers (their inputs are identical up to the conv
     tiles' summation order, which differs between a 2- and a 4-image launch) -- and that without SyncBN they
     are far off.  Further down a randomly initialised batch-stat BN stack amplifies any last-bit difference
-    by ~1.25x per layer (DESIGN.md section 4), so the losses and the update are compared loosely.  det_thresh is
+    by ~1.25x per layer (DESIGN.md section 6), so the losses and the update are compared loosely.  det_thresh is
     set so that nothing is detected: the mask loss sees the ground-truth RoIs only, no NMS decision can differ."""
     import disyolo_oracle as O
     res = {}

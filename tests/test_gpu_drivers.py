@@ -214,3 +214,4 @@ def test_host_feeder_trains_like_set_batch(dev):
     torch.cuda.synchronize()
     np.testing.assert_array_equal(got, want)        # (a NaN step -- zero-area positive RoI, SURVEY B14 -- is NaN in both)
     assert torch.equal(plain.arena, fed.arena) and torch.equal(plain.adam_v, fed.adam_v)
+

@@ -2,7 +2,7 @@
 inputs within a stated fp tolerance" -- the HIP inference path (bf16 storage) against the f32 oracle on a TRAINED net
 at the BASELINE sizes, detection by detection (calculate_test_map.py:218-266 consumes exactly these arrays).
 
-The stated tolerance (DESIGN.md section 4, measured in profiles/r05_e2e_parity.json: the per-pair table):
+The stated tolerance (DESIGN.md section 6, measured in profiles/r05_e2e_parity.json: the per-pair table):
   * >= 95 % of the f32 oracle's detections are found with the same class and box IoU >= 0.75, every one of them
     that is not within 0.1 of the score threshold bar at most one per batch (an NMS survivor can flip between two
     near-duplicate candidates);

@@ -1,6 +1,6 @@
 """The committed tile tables bench.py loads by default (profiles/tune_<workload>.json): keys are conv shape keys, values known
 tile codes; the training tables never pick the persistent streaming kernel (tile 20: it wins on the tuner's single lane and
-loses beside the side lane's resident blocks -- tools/instep_tune.py)."""
+loses beside the side lane's resident blocks -- tools/instep_tune.py, profiles/HISTORY.md, round 4)."""
 import glob
 import json
 import os
