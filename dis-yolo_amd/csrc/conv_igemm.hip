@@ -1718,6 +1718,8 @@ const TileCfg kTiles[] = {
     {9, 64, 128}, {10, 96, 128}, {11, 96, 128}, {12, 192, 128}, {13, 64, 128}, {14, 96, 128}, {15, 192, 128},
     // round 5: two-wave tiles for the deep 1x1 layers whose 64x64 grid is barely one block per CU (18^2: 328 blocks)
     {26, 32, 64}, {27, 64, 32}, {28, 32, 128},
+    // 8 waves of 96x64: 0.42 fragment reads per MFMA against 0.58 for the 48x64 wave tiles (the loop is LDS-read bound)
+    {29, 384, 128},
 };
 // ids 1..15 and 26.. are GEMM tiles of conv_igemm_kernel; 16..25 the patch / streaming / flat-frame kernels
 inline bool is_gemm_tile(int id) { return id < 16 || id >= 26; }
@@ -1808,6 +1810,7 @@ int dispatch(int id, bool bk64, int variant, const ConvParams& p, hipStream_t s)
     DY_TILE(26, 32, 64, 1, 2, 3, 4, 4, 6)
     DY_TILE(27, 64, 32, 2, 1, 3, 4, 4, 6)
     DY_TILE(28, 32, 128, 1, 2, 3, 4, 4, 6)
+    DY_TILE(29, 384, 128, 4, 2, 2, 2, 3, 4)
     default: disyolo_set_error("conv: unknown tile id %d", id); return DISYOLO_E_ARG;
   }
 #endif
@@ -1930,6 +1933,10 @@ extern "C" int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d) {
 
 // stages per (tile id, BK, variant): keep in sync with DY_TILE in dispatch()
 static int tile_stages(int id, bool bk64, int variant) {
+  if (id == 29) {
+    static const int big[4] = {2, 2, 3, 4};
+    return big[(bk64 ? 0 : 2) + (variant ? 1 : 0)];
+  }
   if (id >= 26) {
     static const int two_wave[4] = {3, 4, 4, 6};
     return two_wave[(bk64 ? 0 : 2) + (variant ? 1 : 0)];

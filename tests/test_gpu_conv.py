@@ -101,6 +101,9 @@ CASES = [
     (2, 17, 19, 32, 40, 3, 2, 27),         # ... stride 2, odd sizes, ragged M and N
     (2, 18, 18, 512, 256, 1, 1, 28),       # 32x128 tile (32x64 wave tiles)
     (2, 12, 12, 128, 64, 1, 1, 0x21c),     # ... nk = 2, fewer slices than stages; N smaller than the tile
+    (4, 36, 36, 128, 256, 3, 1, 29),       # 384x128 tile, 8 waves of 96x64 (13.5 M tiles: ragged last one)
+    (2, 18, 18, 96, 72, 3, 1, 29),         # ... BK = 32, ragged channel tile, M smaller than two tiles
+    (1, 16, 16, 1024, 512, 1, 1, 29),      # ... 1x1, one M tile
 ]
 
 
