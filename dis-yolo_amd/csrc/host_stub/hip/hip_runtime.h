@@ -26,4 +26,5 @@ inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { s
 inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { host_stub_log().ops.push_back(3); return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "host stub"; }

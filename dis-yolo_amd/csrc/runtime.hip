@@ -103,7 +103,13 @@ int dy_record(std::function<int(void*)> fn) {
 // DISYOLO_LANE1_LOW=0 keeps it at normal priority (the cut-list data-parallel step does: its RCCL all-reduces are issued on
 // this lane).  lane 2 carries work that must only fill the other lanes' bubbles (the next step's backbone); lane 3 the
 // data-parallel step's RCCL collectives (normal priority).
-static hipStream_t g_pool[NLANES] = {};
+constexpr int MAXDEV = 16;
+static hipStream_t g_pool_dev[MAXDEV][NLANES] = {};      // one pool per device (the product runs one process per GPU; tests may not)
+static hipStream_t* cur_pool() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) dev = 0;
+  return g_pool_dev[dev];
+}
 #ifndef DY_HOST_ONLY
 __global__ void lane_probe_spin_kernel(long long ticks) {     // wall_clock64: 100 MHz
   const long long t0 = wall_clock64();
@@ -154,6 +160,7 @@ static double lane_chain_alone(hipStream_t a) {
 #endif
 static bool pool_lane(int i) {
   if (i <= 0 || i >= NLANES) return false;
+  hipStream_t* g_pool = cur_pool();
   if (g_pool[i]) return true;
   int least = 0, greatest = 0;
   const char* l1 = getenv("DISYOLO_LANE1_LOW");
@@ -203,7 +210,7 @@ static bool ensure_lane(CmdList* c, int i) {
   if (c->side[i]) return true;
   if (!pool_lane(i)) return false;
   if (hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess) return false;
-  c->side[i] = g_pool[i];
+  c->side[i] = cur_pool()[i];
   return true;
 }
 // create the side streams of the lanes in `mask` (bit i = lane i) now, on the current device: call before anything else

@@ -1120,6 +1120,73 @@ class YOLONet(object):
             self._opt_done = [set() for _ in self.opt_chunks]
             self._dp_pending = []        # (slice, mark of its collective on the exchange lane, layer position): exchanged, not yet swept
             self._dp_sweep_delay = int(os.environ.get("DISYOLO_DP_SWEEP_DELAY", "2"))
+        group = max(1, int(os.environ.get("DISYOLO_WGRAD_GROUP", "3")))
+        pending: list = []            # (layer, dx, ld, M, side, pos) whose weight gradients wait for the group's edge
+
+        def flush():
+            if not pending:
+                return
+            side_g = pending[0][4]
+            mark = L.lane_mark(0) if side_g else None         # ONE record on the main lane for the whole group
+            waited = False
+            for (pl, pdx, pld, pM, pside, ppos) in pending:
+                if pside:
+                    if not waited:
+                        L.lane_wait(mark, 1)
+                        waited = True
+                    L.set_lane(1)
+                if pl.kind == "lin":
+                    L.colsum(pl.dx, pl.dbias, pM, L.GRAD_LD, pl.cout, self.ws_aux)   # bias gradient
+                if pl.idx == 1:
+                    if pl.cout == 32 and os.environ.get("DISYOLO_FIRST_WGRAD_MFMA", "1") != "0":
+                        # the first layer's own kernel: taps as the M axis of the MFMA, the f32 image rounded to bf16 on
+                        # its way into LDS (csrc/conv_wgrad.hip, conv_first_wgrad_mfma_kernel)
+                        L.conv_first_wgrad(self.images, pl.dx, pl.dw, self.ws_aux)
+                    else:
+                        # through the im2col kernel: bf16 image padded to 8 channels, K = 9*8 rows of which 27 are real
+                        L.image_pad8(self.images, self._img8)
+                        L.conv2d_wgrad(self._wgrad1_desc, pl.dx, pl.cout, self._dw8, self.ws_aux)
+                        L.copy2d_f32(self._dw8, pl.dw, 9, 3 * pl.cout, 8 * pl.cout, 3 * pl.cout)
+                elif os.environ.get("DISYOLO_EXP_SKIP_WGRAD") not in ("1", "2"):     # (experiment: the step without its weight gradients)
+                    L.conv2d_wgrad(pl.wgrad_desc, pdx, pld, pl.dw, self.ws_aux)
+                if pside:
+                    L.set_lane(0)
+                if self._overlap_rec:
+                    for src, reader in self._xstep_reader.items():
+                        if reader == pl.idx:
+                            L.lane_mark_slot(1 if pside else 0, self._xstep_slot[src])
+                if overlap_opt and pside:
+                    # the optimizer sweep of an arena slice (+ the re-pack of its layers) as soon as the slice's weight
+                    # gradients are final, on the side lane behind them -- not at the end of the critical chain.  It rewrites
+                    # the bf16 operands the data-gradient convs of these layers read: they are all behind the group's edge,
+                    # which the side lane has waited for
+                    ci = self._opt_chunk_of[pl.idx]
+                    self._opt_done[ci].add(pl.idx)
+                    if self._opt_done[ci] == self.opt_chunks[ci]["members"]:
+                        if inl:
+                            # data parallel: the slice's gradients are summed over the ranks first -- the collective goes to
+                            # the exchange lane (behind the side lane's weight gradients of the slice; the side lane itself
+                            # goes on with the next layers' weight gradients), and the sweep of a slice is issued a few
+                            # layers later (DISYOLO_DP_SWEEP_DELAY), on the side lane like the single-GPU step's: its
+                            # collective has had those layers' time on the links before the side lane sits behind it
+                            L.lane_wait(L.lane_mark(1), L.COMM_LANE)
+                            L.set_lane(L.COMM_LANE)
+                            ch = self.opt_chunks[ci]
+                            self.dp.exchange_inlist(ci, ch["off"], ch["cnt"])
+                            self._dp_pending.append((ci, L.lane_mark(L.COMM_LANE), ppos))
+                            L.set_lane(0)
+                        else:
+                            L.set_lane(1)
+                            self._sweep_chunk(ci, 1.0)
+                            L.set_lane(0)
+                if overlap_opt and inl:
+                    # the sweep of a slice follows its collective DISYOLO_DP_SWEEP_DELAY layers later, on the side lane
+                    while self._dp_pending and ppos - self._dp_pending[0][2] >= self._dp_sweep_delay:
+                        self._dp_sweep_oldest(1, main_waited=pside)
+                if on_layer_done is not None:
+                    on_layer_done(pl)
+            pending.clear()
+
         for l in visit:
             pos = order.index(l) if not l.lock else -1
             if l.idx == 82 and getattr(self, "_mask_loss_pending", False):
@@ -1187,32 +1254,12 @@ class YOLONet(object):
             # ordered after that lane only, and both lanes would share ws_aux otherwise)
             tail = 0 if self.dp is not None else self.tail_on_main
             side = self.use_side_lane and (pos < len(order) - tail) and os.environ.get("DISYOLO_EXP_SKIP_WGRAD") != "2"
-            # enqueue order = host order: the data-gradient convs (critical chain, main lane) are issued
-            # before the weight gradient, which only needs dx -- the edge to the side lane is marked here,
-            # before those convs, so the side lane does not wait for them
-            mark = L.lane_mark(0) if side else None
-
-            def weight_gradient():
-                if side:
-                    L.lane_wait(mark, 1)
-                    L.set_lane(1)
-                if l.kind == "lin":
-                    L.colsum(l.dx, l.dbias, M, L.GRAD_LD, l.cout, self.ws_aux)   # bias gradient
-                if l.idx == 1:
-                    if l.cout == 32 and os.environ.get("DISYOLO_FIRST_WGRAD_MFMA", "1") != "0":
-                        # the first layer's own kernel: taps as the M axis of the MFMA, the f32 image rounded to bf16 on
-                        # its way into LDS (csrc/conv_wgrad.hip, conv_first_wgrad_mfma_kernel)
-                        L.conv_first_wgrad(self.images, l.dx, l.dw, self.ws_aux)
-                    else:
-                        # through the im2col kernel: bf16 image padded to 8 channels, K = 9*8 rows of which 27 are real
-                        L.image_pad8(self.images, self._img8)
-                        L.conv2d_wgrad(self._wgrad1_desc, l.dx, l.cout, self._dw8, self.ws_aux)
-                        L.copy2d_f32(self._dw8, l.dw, 9, 3 * l.cout, 8 * l.cout, 3 * l.cout)
-                elif os.environ.get("DISYOLO_EXP_SKIP_WGRAD") not in ("1", "2"):     # (experiment: the step without its weight gradients)
-                    L.conv2d_wgrad(l.wgrad_desc, dx, ld, l.dw, self.ws_aux)
-                if side:
-                    L.set_lane(0)
-
+            # enqueue order = host order: the data-gradient convs (critical chain, main lane) are issued before the
+            # weight gradient, which only needs dx.  The edge to the side lane is an event RECORDED ON THE MAIN LANE, and a
+            # record costs the recording stream ~3 us (tools/micro/event_cost.hip: a chain of 10-us kernels, 11.0 -> 13.8 us
+            # per kernel with a record behind each, 12.0 with one per three): one edge per layer was ~0.1 ms of a 4.1-ms
+            # step.  So the weight gradients of DISYOLO_WGRAD_GROUP consecutive layers share ONE edge, recorded behind the
+            # group's data-gradient convs; the side lane lags a layer or two more, which nothing waits for.
             for mode, tgt, kw in l.dgrad_descs:
                 if mode == "direct":
                     final = (final_of.get(tgt.idx) == (l.idx, "direct") and not tgt.lock and tgt.kind != "lin"
@@ -1224,42 +1271,12 @@ class YOLONet(object):
                     up = tgt
                     L.upsample2x_bwd(kw["tmp"], up.grad, B, l.H, l.W, up.cout, 0, up.cout, accumulate=up.grad_set)
                     up.grad_set = True
-            weight_gradient()
-            if self._overlap_rec:
-                for src, reader in self._xstep_reader.items():
-                    if reader == l.idx:
-                        L.lane_mark_slot(1 if side else 0, self._xstep_slot[src])
-            if overlap_opt and side:
-                # the optimizer sweep of an arena slice (+ the re-pack of its layers) as soon as the slice's
-                # weight gradients are final, on the side lane behind them -- not at the end of the critical
-                # chain.  It rewrites the bf16 operands the data-gradient convs of these layers read: it
-                # waits for the main lane up to this point (all of them are enqueued by now)
-                ci = self._opt_chunk_of[l.idx]
-                self._opt_done[ci].add(l.idx)
-                if self._opt_done[ci] == self.opt_chunks[ci]["members"]:
-                    if inl:
-                        # data parallel: the slice's gradients are summed over the ranks first -- the collective goes to the
-                        # exchange lane (behind the side lane's weight gradients of the slice; the side lane itself goes
-                        # on with the next layers' weight gradients), and the sweep of a slice is issued a few layers
-                        # later (DISYOLO_DP_SWEEP_DELAY), on the side lane like the single-GPU step's: its collective has
-                        # had those layers' time on the links before the side lane sits behind it
-                        L.lane_wait(L.lane_mark(1), L.COMM_LANE)
-                        L.set_lane(L.COMM_LANE)
-                        ch = self.opt_chunks[ci]
-                        self.dp.exchange_inlist(ci, ch["off"], ch["cnt"])
-                        self._dp_pending.append((ci, L.lane_mark(L.COMM_LANE), pos))
-                        L.set_lane(0)
-                    else:
-                        L.lane_wait(L.lane_mark(0), 1)
-                        L.set_lane(1)
-                        self._sweep_chunk(ci, 1.0)
-                        L.set_lane(0)
-            if overlap_opt and inl:
-                # the sweep of a slice follows its collective DISYOLO_DP_SWEEP_DELAY layers later, on the side lane
-                while self._dp_pending and pos - self._dp_pending[0][2] >= self._dp_sweep_delay:
-                    self._dp_sweep_oldest(1)
-            if on_layer_done is not None:
-                on_layer_done(l)
+            if pending and pending[-1][4] != side:
+                flush()
+            pending.append((l, dx, ld, M, side, pos))
+            if not side or len(pending) >= group:
+                flush()
+        flush()
         if not self._overlap_rec:
             L.lane_sync(1, 0)
 
@@ -1380,13 +1397,13 @@ class YOLONet(object):
             ch["pack"].run()
         self._opt_swept.add(ci)
 
-    def _dp_sweep_oldest(self, lane: int) -> None:
+    def _dp_sweep_oldest(self, lane: int, main_waited: bool = False) -> None:
         """data parallel, exchange in the list: the optimizer sweep (+ re-pack) of the slice whose collective was issued
         first, on ``lane`` behind that collective and behind the main lane up to here (the re-pack rewrites operands the
         main lane's data-gradient convs read)"""
         ci, mk = self._dp_pending.pop(0)[:2]
         L.lane_wait(mk, lane)
-        if lane != 0:
+        if lane != 0 and not main_waited:         # (main_waited: the lane already sits behind an edge of the main lane that is late enough)
             L.lane_wait(L.lane_mark(0), lane)
         prev = L.CURRENT_LANE
         L.set_lane(lane)
