@@ -317,6 +317,20 @@ extern "C" int disyolo_cmdlist_end(void) {
   return DISYOLO_OK;
 }
 extern "C" int disyolo_cmdlist_size(void* l) { return l ? (int)((CmdList*)l)->cmds.size() : DISYOLO_E_ARG; }
+// how many queue packets of a kind a replay puts on `lane`: what = 0 launches, 1 event records (marks, slot marks, the record
+// half of a sync), 2 waits (waits, slot waits, the wait half of a sync).  An event packet costs its stream ~3 us
+// (tools/micro/event_cost.hip): a step is designed against these counts, and tests pin them.
+extern "C" int disyolo_cmdlist_count(void* l, int what, int lane) {
+  if (!l || what < 0 || what > 2 || lane < 0 || lane >= NLANES) return DISYOLO_E_ARG;
+  int n = 0;
+  for (const Cmd& k : ((CmdList*)l)->cmds) {
+    if (k.kind == 0) n += what == 0 && k.lane == lane;
+    else if (k.kind == 1) n += (what == 1 && k.from == lane) + (what == 2 && k.to == lane);
+    else if (k.kind == 2 || k.kind == 4) n += what == 1 && k.from == lane;
+    else n += what == 2 && k.to == lane;      // kinds 3, 5
+  }
+  return n;
+}
 extern "C" void* disyolo_cmdlist_lane_stream(void* l, int lane) {
   if (!l || lane < 1 || lane >= NLANES || !ensure_lane((CmdList*)l, lane)) return nullptr;
   return (void*)((CmdList*)l)->side[lane];

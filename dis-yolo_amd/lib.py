@@ -141,6 +141,7 @@ _SIGS = {
     "disyolo_cmdlist_begin": (C.c_int, [C.c_void_p]),
     "disyolo_cmdlist_end": (C.c_int, []),
     "disyolo_cmdlist_size": (C.c_int, [C.c_void_p]),
+    "disyolo_cmdlist_count": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "disyolo_cmdlist_set_lane": (C.c_int, [C.c_int]),
     "disyolo_cmdlist_sync": (C.c_int, [C.c_int, C.c_int]),
     "disyolo_cmdlist_mark": (C.c_int, [C.c_int]),
@@ -276,6 +277,10 @@ class CmdList:
 
     def size(self) -> int:
         return load().disyolo_cmdlist_size(self.h)
+
+    def count(self, what: str, lane: int) -> int:
+        """packets a replay puts on ``lane``: what = "launches" | "records" | "waits" """
+        return load().disyolo_cmdlist_count(self.h, {"launches": 0, "records": 1, "waits": 2}[what], lane)
 
     def run(self, first: int = 0, last: Optional[int] = None, fork: bool = True, join: bool = True) -> None:
         last = self.size() if last is None else last

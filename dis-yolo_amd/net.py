@@ -654,9 +654,9 @@ class YOLONet(object):
                 elif l.idx in (60, 68, 76):
                     L.set_lane(0)
             if self._overlap_rec:
-                if l.idx in self._xstep_slot and (l.idx not in plan or plan[l.idx] is not None):
-                    L.lane_wait_slot(self._xstep_slot[l.idx], 0)      # the previous replay's last reader of this layer's output
-                if l.idx == self._xstep_first_trainable:
+                if l.idx in self._xstep_waits and (l.idx not in plan or plan[l.idx] is not None):
+                    L.lane_wait_slot(self._xstep_waits[l.idx], 0)     # the previous replay's last reader of this layer's output
+                if l.idx == self._xstep_first_trainable and not self._xstep_all_merged:
                     L.lane_wait_slot(self.SLOT_ALL, 0)                # the previous replay's optimizer + re-pack
             if l.idx in plan:
                 if plan[l.idx] is not None:
@@ -701,6 +701,23 @@ class YOLONet(object):
         for src in self._xstep_slot:
             readers = [x.idx for x in self.layers if x.idx > P and src in (x.src, x.src_up, x.shortcut)]
             self._xstep_reader[src] = max(readers, key=order.index)
+        # where the next replay's main lane waits.  A wait that is enqueued before its event has completed costs the waiting
+        # stream ~3 us whether or not it ever blocks (tools/micro/event_cost.hip), so the waits are merged: the side lane is
+        # FIFO, hence ONE wait -- in front of the first of these backbone layers -- on the slot whose reader comes latest in
+        # the backward pass covers all of them; a source whose last reader is the backward pass's LAST layer can only be
+        # released by the end of the tail: the wait for the whole tail moves up to it (one backbone layer less of overlap)
+        self._xstep_waits = {src: s for src, s in self._xstep_slot.items()}
+        self._xstep_all_merged = False
+        if self.use_side_lane and self.tail_on_main == 0 and self._xstep_slot and os.environ.get("DISYOLO_XSTEP_MERGE", "1") != "0":
+            late = [src for src in self._xstep_slot if self._xstep_reader[src] == order[-1]]
+            early = [src for src in self._xstep_slot if src not in late]
+            self._xstep_waits = {}
+            if early:
+                last = max(early, key=lambda src: order.index(self._xstep_reader[src]))
+                self._xstep_waits[min(early)] = self._xstep_slot[last]
+            if late:
+                self._xstep_waits[min(late)] = self.SLOT_ALL
+                self._xstep_all_merged = True
 
     def _forward_first_two(self) -> None:
         l1, l2 = self.by_idx[1], self.by_idx[2]

@@ -480,6 +480,8 @@ void disyolo_cmdlist_destroy(void* list);
 int disyolo_cmdlist_begin(void* list);
 int disyolo_cmdlist_end(void);
 int disyolo_cmdlist_size(void* list);
+/* packets a replay puts on `lane`: what = 0 launches, 1 event records, 2 event waits (an event packet costs its stream ~3 us) */
+int disyolo_cmdlist_count(void* list, int what, int lane);
 /* four lanes: 0 = the stream passed to cmdlist_run, 1..3 = side streams owned by the list (3 = the gradient exchange).
  * set_lane selects the lane of the launches recorded next; sync(from,to) makes lane `to` wait
  * for what lane `from` has recorded so far.  Both are no-ops outside a recording.  Every

@@ -603,6 +603,20 @@ def test_overlapped_tail_replays_without_a_join_in_between(dev, stage, B, S, fee
     assert int(over.step_count) == n
 
 
+def test_recorded_step_keeps_event_packets_off_the_main_lane(dev):
+    """An event record or an early-enqueued wait costs its stream ~3 us (tools/micro/event_cost.hip); rounds 1-4 put one
+    record per trainable layer on the main lane (35 + 8 waits in stage 1).  The step is designed against these counts:
+    one edge per DISYOLO_WGRAD_GROUP (3) layers' weight gradients, the three head branches, the mask-loss input, the tail;
+    cross-replay waits merged to two."""
+    for stage, max_rec, max_wait in ((1, 16, 4), (2, 34, 3)):
+        net = YOLONet(training=True, device=dev, image_size=64, batch_size=2, stage=stage, seed=2)
+        net.set_batch(O.synthetic_batch(2, 64, seed=3))
+        net.build_program(det_thresh=0.1, overlap_tail=True)
+        rec, wait = net._prog.count("records", 0), net._prog.count("waits", 0)
+        assert rec <= max_rec and wait <= max_wait, (stage, rec, wait)
+        assert net._prog.count("launches", 1) > 40          # (the side lane does carry the weight gradients)
+
+
 def test_device_shuffle_produces_fresh_uniform_permutations(dev):
     B = 64
     pd = torch.zeros(B, 30, dtype=torch.int32, device=dev)

@@ -25,12 +25,20 @@ int main() {
   spin<<<1, 64, 0, side>>>(100);
   (void)hipEventRecord(done, side);
   (void)hipDeviceSynchronize();
-  for (int mode = 0; mode < 7; ++mode) {
+  hipEvent_t late;
+  (void)hipEventCreateWithFlags(&late, hipEventDisableTiming);
+  for (int mode = 0; mode < 9; ++mode) {
     double best = 1e30;
     for (int rep = 0; rep < 5; ++rep) {
       (void)hipDeviceSynchronize();
+      if (mode >= 7) {      // an event that is NOT complete when the waits are enqueued (behind a 2-ms kernel on the side stream)
+        spin<<<1, 64, 0, side>>>(2000 * 100);
+        (void)hipEventRecord(late, side);
+      }
       const double t0 = now();
       for (int i = 0; i < N; ++i) {
+        if (mode == 7) (void)hipStreamWaitEvent(0, late, 0);
+        if (mode == 8 && (i == 0 || i % 3 == 2)) (void)hipStreamWaitEvent(0, late, 0);
         spin<<<1, 64, 0, 0>>>(10 * 100);
         if (mode == 5) (void)hipStreamWaitEvent(0, done, 0);          // the main stream waits for an event that completed long ago
         if (mode == 6 && i % 3 == 2) (void)hipStreamWaitEvent(0, done, 0);
@@ -50,8 +58,10 @@ int main() {
     }
     const char* what[] = {"chain alone", "+ an event record after every kernel", "+ a side stream waiting on each event, one kernel behind it",
                           "+ an event record after every 3rd kernel", "+ a side stream waiting on every 3rd",
-                          "+ a wait for a long-completed event before every kernel", "+ such a wait before every 3rd kernel"};
-    printf("%-62s main stream done after %.0f us = %.2f us per kernel\n", what[mode], best, best / N);
+                          "+ a wait for a long-completed event before every kernel", "+ such a wait before every 3rd kernel",
+                          "+ a wait, ENQUEUED EARLY, for a 2-ms-late event before every kernel (minus 2000)", "+ such a wait before every 3rd (minus 2000)"};
+    if (mode >= 7) best -= 2000.0;
+    printf("%-86s main stream done after %.0f us = %.2f us per kernel\n", what[mode], best, best / N);
   }
   return 0;
 }
