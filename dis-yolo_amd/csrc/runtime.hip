@@ -102,7 +102,8 @@ int dy_record(std::function<int(void*)> fn) {
 // stream priority, so the chain's kernels get the CU slots first when both have blocks pending (+1.5-2 % measured).
 // DISYOLO_LANE1_LOW=0 keeps it at normal priority (the cut-list data-parallel step does: its RCCL all-reduces are issued on
 // this lane).  lane 2 carries work that must only fill the other lanes' bubbles (the next step's backbone); lane 3 the
-// data-parallel step's RCCL collectives (normal priority).
+// data-parallel step's RCCL collectives and the optimizer sweeps behind them (lowest priority like lane 1: the HBM-bound sweeps
+// must not compete with the main lane -- one RCCL rank: 4.22 -> 4.17 ms, the plain step's time; DISYOLO_LANE3_LOW=0: normal).
 constexpr int MAXDEV = 16;
 static hipStream_t g_pool_dev[MAXDEV][NLANES] = {};      // one pool per device (the product runs one process per GPU; tests may not)
 static hipStream_t* cur_pool() {
@@ -166,7 +167,7 @@ static bool pool_lane(int i) {
   const char* l1 = getenv("DISYOLO_LANE1_LOW");
   const bool lane1_low = !(l1 && l1[0] == '0');
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;   // no device (CPU-only build check)
-  const bool low = (i == 2 && getenv("DISYOLO_LANE2_LOW")) || (i == 1 && lane1_low);
+  const bool low = (i == 2 && getenv("DISYOLO_LANE2_LOW")) || (i == 1 && lane1_low) || (i == 3 && !(getenv("DISYOLO_LANE3_LOW") && getenv("DISYOLO_LANE3_LOW")[0] == '0'));
   const int prio = low ? least : 0;
 #ifndef DY_HOST_ONLY
   const char* pe = getenv("DISYOLO_LANE_PROBE");

@@ -1137,6 +1137,10 @@ class YOLONet(object):
             self._opt_done = [set() for _ in self.opt_chunks]
             self._dp_pending = []        # (slice, mark of its collective on the exchange lane, layer position): exchanged, not yet swept
             self._dp_sweep_delay = int(os.environ.get("DISYOLO_DP_SWEEP_DELAY", "2"))
+            # where a slice's sweep runs: "comm" = on the exchange lane right behind the slice's collective (default: a hop
+            # between lanes costs ~15 us, profiles/r05_hw_queues.txt, and the side lane is nearly as busy as the main one),
+            # "side" = back on the side lane DISYOLO_DP_SWEEP_DELAY layers later
+            self._dp_sweep_on_comm = self._dp_sweep_lane() != 1
         group = max(1, int(os.environ.get("DISYOLO_WGRAD_GROUP", "3")))
         pending: list = []            # (layer, dx, ld, M, side, pos) whose weight gradients wait for the group's edge
 
@@ -1190,7 +1194,13 @@ class YOLONet(object):
                             L.set_lane(L.COMM_LANE)
                             ch = self.opt_chunks[ci]
                             self.dp.exchange_inlist(ci, ch["off"], ch["cnt"])
-                            self._dp_pending.append((ci, L.lane_mark(L.COMM_LANE), ppos))
+                            if self._dp_sweep_on_comm:
+                                # ... and the sweep right behind it on the exchange lane (lowest stream priority, like the side
+                                # lane the single-GPU step sweeps on): the side lane never waits for the links; its mark sits
+                                # behind the group's main-lane edge, so the re-pack is safe
+                                self._sweep_chunk(ci, 1.0 / self.dp.world_size)
+                            else:
+                                self._dp_pending.append((ci, L.lane_mark(L.COMM_LANE), ppos))
                             L.set_lane(0)
                         else:
                             L.set_lane(1)
@@ -1414,6 +1424,16 @@ class YOLONet(object):
             ch["pack"].run()
         self._opt_swept.add(ci)
 
+    def _dp_sweep_lane(self) -> int:
+        """data parallel, exchange in the list: the lane a slice's optimizer sweep runs on.  DISYOLO_DP_SWEEP_LANE = "comm"
+        (default): the exchange lane itself, right behind the slice's collective -- the side lane never waits for the links;
+        that lane has the lowest stream priority (DISYOLO_LANE3_LOW=0: normal), so the HBM-bound sweeps do not compete with
+        the main lane, as on the single-GPU step's side lane.  One RCCL rank, same box, ms per step: plain 4.16-4.18 |
+        comm + low priority 4.17-4.18 | comm at normal priority 4.22 | "side" (back on the side lane
+        DISYOLO_DP_SWEEP_DELAY layers later) 4.20 | a third, low-priority lane for the sweeps behind a normal-priority
+        exchange lane 4.15-4.18 against 4.12 for comm + low on another box (one more 15-us hop): not kept."""
+        return 1 if os.environ.get("DISYOLO_DP_SWEEP_LANE", "comm") == "side" else L.COMM_LANE
+
     def _dp_sweep_oldest(self, lane: int, main_waited: bool = False) -> None:
         """data parallel, exchange in the list: the optimizer sweep (+ re-pack) of the slice whose collective was issued
         first, on ``lane`` behind that collective and behind the main lane up to here (the re-pack rewrites operands the
@@ -1437,10 +1457,25 @@ class YOLONet(object):
             if self.opt_chunks is None:
                 self._plan_opt_chunks()
             nt = self.n_params - self.n_decay       # batch-norm gamma / beta: not regularised
-            if self.dp is not None and self.dp.inlist:
+            inl = self.dp is not None and self.dp.inlist
+            on_comm = inl and self._dp_sweep_lane() != 1
+            cur = L.CURRENT_LANE
+            if inl and on_comm:
+                # what is left of the exchange and of the optimizer on the exchange lane, in order: each remaining slice's
+                # collective and its sweep, gamma / beta, the finish; this lane then waits for the exchange lane once
+                sl = L.COMM_LANE
+                L.lane_wait(L.lane_mark(cur), L.COMM_LANE)
+                L.set_lane(L.COMM_LANE)
+                for ci in range(len(self.opt_chunks)):
+                    if ci not in self._opt_swept:
+                        ch = self.opt_chunks[ci]
+                        self.dp.exchange_inlist(ci, ch["off"], ch["cnt"])
+                        self._sweep_chunk(ci, grad_scale)
+                if nt > 0:
+                    self.dp.exchange_inlist("tail", self.n_decay, nt)
+            elif inl:
                 # the collectives of everything not exchanged yet (the slices that became final last, gamma / beta) on the
                 # exchange lane, behind what this lane has seen; the sweeps follow on this lane, oldest collective first
-                cur = L.CURRENT_LANE
                 pend = {p[0] for p in self._dp_pending}
                 L.lane_wait(L.lane_mark(cur), L.COMM_LANE)
                 L.set_lane(L.COMM_LANE)
@@ -1466,6 +1501,9 @@ class YOLONet(object):
             L.adam_finish(self.step_dev, self._opt_parts if self.n_decay else None, self._opt_nparts if self.n_decay else 0,
                           self.l2, self.reg_loss if self.n_decay else None,
                           record=(self.losses, self.mask_loss, None if self.n_decay else self.reg_loss, self.loss_ring))
+            if inl and on_comm:
+                L.set_lane(cur)
+                L.lane_sync(sl, cur)
             self._opt_swept = set()
             self._opt_done = [set() for _ in self.opt_chunks]
             self._dp_pending = []
