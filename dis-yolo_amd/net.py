@@ -1174,7 +1174,7 @@ class YOLONet(object):
                     L.set_lane(0)
                 if self._overlap_rec:
                     for src, reader in self._xstep_reader.items():
-                        if reader == pl.idx:
+                        if reader == pl.idx and self._xstep_slot[src] in self._xstep_waits.values():     # (only slots somebody waits on)
                             L.lane_mark_slot(1 if pside else 0, self._xstep_slot[src])
                 if overlap_opt and pside:
                     # the optimizer sweep of an arena slice (+ the re-pack of its layers) as soon as the slice's weight
