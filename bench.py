@@ -361,6 +361,15 @@ def secondary_measurements(args, dev):
                                   "frac_of_mfma_peak": d["model_flops"]["frac_of_mfma_peak"], "process": "child"}
     except Exception as e:
         out["infer_b32_graph"] = {"error": repr(e)[:200]}
+    # BASELINE.json configs[0] on the GPU: one 576x576 image through network + detection filter + mask assembly (what
+    # calculate_test_map.py:218 runs per test image); the CPU oracle's number for the same call is cpu_baseline.config1_forward
+    try:
+        d = child(["--task", "infer", "--batch", "1"])
+        out["infer_b1_graph"] = {"workload": d["config"]["workload"] + "_hipgraph (BASELINE configs[0] on the GPU)",
+                                 "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                                 "steps": d["steps"], "repeats": 5, "process": "child"}
+    except Exception as e:
+        out["infer_b1_graph"] = {"error": repr(e)[:200]}
     return out
 
 
