@@ -712,6 +712,8 @@ def main():
         emit(out)
     if use_dp:
         torch.cuda.synchronize()
+        if net.dp is not None and net.dp.comm is not None:
+            net.dp.comm.close()
         dist.destroy_process_group()
 
 

@@ -1089,9 +1089,20 @@ class Comm:
         self.h, self.rank, self.world = h, rank, world
 
     def close(self) -> None:
+        """destroy the communicator (a collective: every rank must call it); device work that uses it is drained first"""
         if getattr(self, "h", None):
+            torch.cuda.synchronize()
             _check(load().disyolo_comm_destroy(self.h), "comm_destroy")
             self.h = None
+
+    def __del__(self):
+        # a dropped communicator is released like a closed one (its buffers are device memory); at interpreter exit the
+        # runtime may already be gone: never raise from here
+        try:
+            if getattr(self, "h", None) and torch.cuda.is_available():
+                self.close()
+        except Exception:
+            pass
 
     def allreduce(self, t: torch.Tensor) -> None:
         """t = sum over the ranks (in place), on the current stream / lane"""
