@@ -49,3 +49,18 @@ def test_argument_errors_are_reported_not_thrown():
     assert lib.disyolo_cmdlist_run(None, 0, 0, None) == -1
     assert lib.disyolo_adam_step(None, None, None, None, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 1.0, None) == -1
     assert lib.disyolo_detect_workspace(8, 576, 3) > 8 * 20412 * 24
+
+
+def test_exchange_entry_points_validate_and_resolve_rccl_without_a_gpu():
+    """csrc/comm.hip: RCCL is resolved at run time (no link-time dependency: the library above loaded without it being named),
+    argument errors come back as codes, and nothing here computes or needs a device"""
+    lib = L.load()
+    assert L.comm_load() >= 20000                     # RCCL's version code (2.x.y -> 2xxyy), from the copy torch ships
+    buf = ctypes.create_string_buffer(64)
+    assert lib.disyolo_comm_allreduce_sum(None, buf, 16, 0, None) == -1 and b"comm_allreduce_sum" in lib.disyolo_last_error()
+    assert lib.disyolo_comm_allreduce_sum(buf, buf, 16, 7, None) == -1              # unknown dtype code
+    assert lib.disyolo_comm_init(buf, 3, 2, None) == -1                               # rank >= nranks / null output
+    assert lib.disyolo_comm_destroy(None) == 0
+    assert lib.disyolo_cast_f32_bf16(None, buf, 4, None) == -1
+    assert lib.disyolo_cmdlist_count(None, 0, 0) == -1
+    assert lib.disyolo_cmdlist_lane_stream(None, 1) is None
