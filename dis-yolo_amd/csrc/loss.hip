@@ -34,8 +34,15 @@ struct YoloLossParams {
   float inv_B;
 };
 
-// one thread = one (cell, anchor); blockIdx.y = image
-__global__ __launch_bounds__(256) void yolo_loss_kernel(YoloLossParams p) {
+// one thread = one (cell, anchor); blockIdx.y = image.  The three scales run as ONE launch (round 5: three dependent launches
+// at the forward / backward boundary of the main lane were 44 us where the longest scale takes 24): block bx of scale s,
+// whose grid is gx blocks wide -- the partial rows keep the layout of the three separate launches, so the sums are the same
+// bit for bit.
+struct YoloLoss3 {
+  YoloLossParams p[3];
+  int gx[3];
+};
+__device__ __forceinline__ void yolo_loss_body(const YoloLossParams& p, const int bx, const int gx) {
   __shared__ float s_tb[64 * 4];
   __shared__ float s_red[4][5];
   const int b = blockIdx.y;
@@ -46,7 +53,7 @@ __global__ __launch_bounds__(256) void yolo_loss_kernel(YoloLossParams p) {
   __syncthreads();
   const int D = 5 + p.C;
   const int ncell = p.g * p.g;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int idx = bx * 256 + threadIdx.x;
   float l_obj = 0.f, l_noobj = 0.f, l_cls = 0.f, l_xy = 0.f, l_wh = 0.f;
   if (idx < ncell * 3) {
     const int a = idx % 3, cell = idx / 3;
@@ -130,8 +137,20 @@ __global__ __launch_bounds__(256) void yolo_loss_kernel(YoloLossParams p) {
   __syncthreads();
   if (threadIdx.x < 5) {
     const float v = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
-    p.partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 5 + threadIdx.x] = v;
+    p.partial[((size_t)blockIdx.y * gx + bx) * 5 + threadIdx.x] = v;
   }
+}
+__global__ __launch_bounds__(256) void yolo_loss_kernel(YoloLoss3 P) {
+  int bx = blockIdx.x, s = 0;
+  if (bx >= P.gx[0]) {
+    bx -= P.gx[0];
+    s = 1;
+    if (bx >= P.gx[1]) {
+      bx -= P.gx[1];
+      s = 2;
+    }
+  }
+  yolo_loss_body(P.p[s], bx, P.gx[s]);
 }
 
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -430,9 +449,10 @@ extern "C" int disyolo_yolo_loss(const float* const logits[3], const float* cons
   const int gs[3] = {4 * g1, 2 * g1, g1};
   float* part = (float*)workspace;
   int nblk[3];
+  YoloLoss3 P;
   for (int s = 0; s < 3; ++s) {
     DY_REQUIRE(logits[s] && labels[s] && dlogits[s], "yolo_loss: null tensor for scale %d", s);
-    YoloLossParams p;
+    YoloLossParams& p = P.p[s];
     p.logits = logits[s];
     p.labels = labels[s];
     p.true_boxes = true_boxes;
@@ -446,12 +466,12 @@ extern "C" int disyolo_yolo_loss(const float* const logits[3], const float* cons
     p.ignore_thresh = ignore_thresh;
     p.obj_scale = scales[0]; p.noobj_scale = scales[1]; p.class_scale = scales[2]; p.coord_scale = scales[3];
     p.inv_B = 1.f / (float)B;
-    const int gx = ceil_div(gs[s] * gs[s] * 3, 256);
-    nblk[s] = gx * B;
-    hipLaunchKernelGGL(yolo_loss_kernel, dim3(gx, B), dim3(256), 0, st, p);
-    DY_CHECK_LAUNCH();
+    P.gx[s] = ceil_div(gs[s] * gs[s] * 3, 256);
+    nblk[s] = P.gx[s] * B;
     part += (size_t)nblk[s] * 5;
   }
+  hipLaunchKernelGGL(yolo_loss_kernel, dim3(P.gx[0] + P.gx[1] + P.gx[2], B), dim3(256), 0, st, P);
+  DY_CHECK_LAUNCH();
   hipLaunchKernelGGL(yolo_loss_final_kernel, dim3(1), dim3(320), 0, st, (const float*)workspace,
                      nblk[0] + nblk[1] + nblk[2], 1.f / (float)B, losses);
   DY_CHECK_LAUNCH();
