@@ -350,7 +350,11 @@ def secondary_measurements(args, dev):
                         "ms_per_step": d["ms_per_step"], "steps": d["steps"], "repeats": d.get("repeats"), "dtype": d["dtype"],
                         "frac_of_mfma_peak": round(gf * d["value"] / 1e3 / MFMA_PEAK_TFLOPS, 4),
                         "loss_first": d["config"].get("loss_first"), "loss_last": d["config"].get("loss_last"),
-                        "conv_tiles": d["config"].get("conv_tiles"), "process": "child"}
+                        "conv_tiles": d["config"].get("conv_tiles"), "process": "child",
+                        "role": ("BASELINE configs[4] at its per-GPU size as this package runs it: bf16 is the faster path here"
+                                 if dt == "bf16" else
+                                 "the e4m3 backbone OPTION (parity-tested forward of conv1-52): slower than bf16 at 4 images per GPU, "
+                                 "where the backbone is 28 % of the step and fixed-cost dominated (DESIGN.md section 8)")}
         except Exception as e:
             out[key] = {"error": repr(e)[:200]}
     try:
