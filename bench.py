@@ -386,6 +386,46 @@ def emit(obj) -> None:
 _REAL_STDOUT = 1
 
 
+
+def spawn_workers(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` as a child process (stdout / stderr inherited: rank 0's
+    JSON line is the child's only stdout) and exit with its code.  The parent never initialises the GPU."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = str(so.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between the ranks on this pool
+    print("bench.py: --gpus %d without WORLD_SIZE: spawning %s" % (n, " ".join(cmd[1:9])), file=sys.stderr)
+    rc = subprocess.call(cmd, env=env, stdout=_REAL_STDOUT)     # (fd 1 of this process points at stderr: main())
+    sys.exit(rc)
+
+
+def dry_launch(world: int, rank: int, local_rank: int) -> int:
+    """what the N > 1 launch path hands every rank, checked without a GPU: a gloo group over the launcher's rendezvous,
+    every rank's environment gathered on rank 0, one JSON line"""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = {"rank": rank, "local_rank": local_rank, "world_size": world, "pid": os.getpid(),
+            "master": "%s:%s" % (os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"]),
+            "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+            "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+    seen = [None] * world
+    dist.all_gather_object(seen, mine)
+    dist.barrier()
+    if rank == 0:
+        emit({"dry_launch": True, "n_gpus": world, "ranks": seen})
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     global _REAL_STDOUT
     sys.stdout.flush()
@@ -447,15 +487,23 @@ def main():
                     help="how the step is driven: the recorded command list replayed by the native executor "
                          "(default; cut at the all-reduce points when N > 1), its hipGraph capture, or per-launch "
                          "Python calls")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launch self-test (no GPU): every rank reports its RANK / LOCAL_RANK / WORLD_SIZE over a gloo group and "
+                         "rank 0 prints them as one JSON line")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` typed bare: start the N workers ourselves, the way the driver would
+        # (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1), as a CHILD process -- nothing in this
+        # process has touched the GPU yet and nothing is exec'ed -- and hand its output and exit code through
+        return spawn_workers(args.gpus)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry_launch:
+        return dry_launch(world, rank, local_rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dp = world > 1 or args.force_dp
@@ -581,6 +629,17 @@ def main():
         torch.cuda.synchronize()
         dp_trace = net.dp.trace_summary()
         net.dp.trace = None
+    if net.dp is not None and dp_trace is not None:
+        # how many ranks the exchange really spans: a vector of ones summed through the step's OWN communicator (the kernel
+        # library's RCCL communicator when the exchange is in the list, torch.distributed's otherwise) -- a line whose
+        # collectives moved nothing (one rank) says so itself
+        ones = torch.ones(16, device=dev)
+        if net.dp.comm is not None:
+            net.dp.comm.allreduce(ones)
+        else:
+            dist.all_reduce(ones)
+        torch.cuda.synchronize()
+        dp_trace["ranks_seen_by_rccl"] = int(round(float(ones[0].cpu())))
     finite = bool(np.all(np.isfinite(loss_trace))) and bool(torch.isfinite(net.arena).all())
     if world > 1:
         f = torch.tensor([1.0 if finite else 0.0], device=dev)
