@@ -33,6 +33,21 @@ struct ConvParams {
   int xcd_n;                 // GEMM tiles: an XCD's run of tiles walks the pixel tiles of a few channel tiles (weights > input)
   int flags;
   float alpha;
+  // DISYOLO_CONV_BN_FUSED / DISYOLO_CONV_BN_BWD_FUSED: batch norm inside the launch (cluster exchange below)
+  void* y_act;
+  const float* gamma;
+  const float* beta;
+  float* mm;
+  float* mv;
+  float* o_scale;
+  float* o_shift;
+  float* o_mean;
+  float* o_rstd;
+  float* dgamma;
+  float* dbeta;
+  unsigned* csync;
+  float bn_decay, bn_eps;
+  double inv_count;          // 1 / (B*Ho*Wo)
 };
 
 // swizzle of the 16-byte chunk index inside one LDS row: 64-byte rows (BK=32) use a 4-entry
@@ -103,6 +118,128 @@ static __device__ __forceinline__ void stats_out(const ConvParams& p, int row, i
 static __device__ __forceinline__ void bnpart_out(const ConvParams& p, int row, int n, float s, float s2) {
   p.bn_part[((size_t)row * p.Cout + n) * 2 + 0] = s;
   p.bn_part[((size_t)row * p.Cout + n) * 2 + 1] = s2;
+}
+
+// ---- cluster exchange: the blocks of ONE launch that share a channel tile hand each other a row of per-channel partial
+// sums (batch statistics, batch-norm backward sums) and each of them sums ALL rows in the same fixed order -- a reduction
+// over the M tiles without a second launch.  Protocol (MI355X_MICROARCH.md "Valid forms", row 1; cdna_hip_programming.md
+// Guideline 16 R1): the payload is stored write-through (agent-scope relaxed atomic stores = `global_store ... sc1`: the
+// bytes leave this XCD's L2), every storing wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at its barrier,
+// ONE lane adds 1 to the tile's arrival counter (agent scope); a consumer polls that counter with relaxed agent-scope loads
+// (`sc1`: served past the L1) from one lane, meets its workgroup at a barrier, and reads the rows with `sc1` loads ONLY
+// (nothing of the payload is ever read through the L1, whose lines other CUs' stores never refresh).  No fences.  The rows'
+// lines cannot sit stale in an L2: nobody reads them in this launch before the counter says they are there, and a launch
+// boundary has invalidated whatever an earlier launch cached.  Counters: [tile][32 words] = one 128-byte line per channel
+// tile, word 0 = arrivals, word 1 = departures; the block whose departure is the last one zeroes both, so a buffer zeroed
+// ONCE stays valid launch after launch (nothing here depends on a per-launch argument: the launches are replayed from a
+// recorded list with frozen arguments).  Every wait is bounded: on a time-out the error word (after the last tile's line)
+// gets a code and the launch runs on with whatever it has -- wrong numbers and a loud host-side error instead of a hung GPU.
+// Residency: every block of a cluster must be resident before any of them can leave the wait -- the launcher admits the
+// fused epilogue only when the WHOLE grid fits on the device at once (disyolo_conv2d_bn_fused_ok).
+typedef __attribute__((address_space(1))) unsigned gu32;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+constexpr int CL_LINE = 32;                      // words per channel tile
+constexpr unsigned CL_SPIN_LIMIT = 1u << 21;     // polls of ~0.25 us: half a second
+static __device__ __forceinline__ gu32* cl_word(unsigned* base, int idx) {
+  return (gu32*)(size_t)(base + idx);
+}
+// one row entry (two floats) written through to memory
+static __device__ __forceinline__ void cl_store2(float* p2, float a, float b) {
+  const unsigned long long v = ((unsigned long long)__builtin_bit_cast(unsigned, b) << 32) | __builtin_bit_cast(unsigned, a);
+  __hip_atomic_store((gu64*)(size_t)p2, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ void cl_load2(const float* p2, float& a, float& b) {
+  const unsigned long long v = __hip_atomic_load((gu64*)(size_t)p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  a = __builtin_bit_cast(float, (unsigned)v);
+  b = __builtin_bit_cast(float, (unsigned)(v >> 32));
+}
+// after the block's row is stored (cl_store2 by any of its waves): publish it
+static __device__ __forceinline__ void cl_arrive(unsigned* csync, int tile) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY storing wave drains its write-through stores
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(cl_word(csync, tile * CL_LINE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wait until `expect` blocks have published; all threads of the block return together, then read rows with cl_load2 only
+static __device__ __forceinline__ void cl_wait(unsigned* csync, int tile, unsigned expect, int err_idx) {
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(cl_word(csync, tile * CL_LINE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > CL_SPIN_LIMIT) {
+        __hip_atomic_store(cl_word(csync, err_idx), 0xC1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+// after the block has read every row: the last block to leave re-arms the counters for the next launch
+static __device__ __forceinline__ void cl_depart(unsigned* csync, int tile, unsigned expect) {
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(cl_word(csync, tile * CL_LINE + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == expect) {
+      __hip_atomic_store(cl_word(csync, tile * CL_LINE), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(cl_word(csync, tile * CL_LINE + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+// Sum rows [0, rows) of part[row][C][2] for the BN channels n0 .. n0+BN of this block, f64, fixed order, by all T threads:
+// thread = (channel cl = tid % BN, row group g = tid / BN); group g takes rows g, g+G, ...; the groups are combined in
+// order through `scratch` (T*16 bytes of LDS).  The result of channel cl is returned to the threads with g == 0.
+// Every block of the cluster runs exactly this code on exactly these bytes: all of them get the same bits.
+template <int T, int BN>
+static __device__ __forceinline__ bool cl_sum_rows(const float* part, int rows, int C, int n0, double* scratch, double& r0, double& r1) {
+  static_assert(T % BN == 0, "threads per block must be a multiple of the channel tile");
+  constexpr int G = T / BN;
+  const int cl = threadIdx.x % BN, g = threadIdx.x / BN;
+  const int n = n0 + cl;
+  double a0 = 0.0, a1 = 0.0;
+  if (n < C) {
+    int r = g;
+    for (; r + 7 * G < rows; r += 8 * G) {      // eight independent loads in flight
+      float v0[8], v1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cl_load2(part + ((size_t)(r + u * G) * C + n) * 2, v0[u], v1[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a0 += (double)v0[u];
+        a1 += (double)v1[u];
+      }
+    }
+    for (; r < rows; r += G) {
+      float v0, v1;
+      cl_load2(part + ((size_t)r * C + n) * 2, v0, v1);
+      a0 += (double)v0;
+      a1 += (double)v1;
+    }
+  }
+  scratch[(g * BN + cl) * 2 + 0] = a0;
+  scratch[(g * BN + cl) * 2 + 1] = a1;
+  __syncthreads();
+  if (g == 0 && n < C) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      s0 += scratch[(k * BN + cl) * 2 + 0];
+      s1 += scratch[(k * BN + cl) * 2 + 1];
+    }
+    r0 = s0;
+    r1 = s1;
+    return true;
+  }
+  return false;
+}
+// batch statistics -> the layer's (scale, shift): the arithmetic of bn_finalize_kernel (bn.hip), value for value
+static __device__ __forceinline__ void cl_bn_coeffs(double s, double s2, double inv_count, float gamma, float beta, float eps,
+                                                    float& sc, float& sh, float& meanf, float& varf, float& rstd) {
+  const double mean = s * inv_count;
+  double var = s2 * inv_count - mean * mean;   // population variance (tf.nn.moments)
+  if (var < 0.0) var = 0.0;
+  meanf = (float)mean;
+  varf = (float)var;
+  rstd = 1.0f / sqrtf(varf + eps);
+  sc = gamma * rstd;
+  sh = beta - meanf * sc;
 }
 
 // batch-norm backward sums of one stored 16-byte chunk (8 channels of one pixel): g = dy*act'(z), xhat

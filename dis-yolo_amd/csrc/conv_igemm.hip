@@ -30,7 +30,11 @@ namespace {
 // accumulators are summed through LDS (fixed order) before group 0 runs the epilogue.  It
 // doubles the waves per CU for the layers whose M*N gives barely one block per CU (18^2, 36^2),
 // where one wave per SIMD cannot overlap its DMA issue with its MFMAs.
-template <int BM, int BN, int WM, int WN, int BK, int ST, int KS, int KG = 1>
+// EPI = 1: the instance that carries the fused batch-norm BACKWARD epilogue (DISYOLO_CONV_BN_BWD_FUSED).  Its own instance
+// because that epilogue holds ~90 registers live (four coefficient vectors, two sum vectors and the target's conv output per
+// lane): inside the plain instances it cost the 1x1 tiles 40-60 registers and a wave per SIMD (64x128: 108 -> 152) and made
+// the three-blocks-per-CU 128x128 tiles spill.  Only the tiles the data-gradient convs of the small maps use have one.
+template <int BM, int BN, int WM, int WN, int BK, int ST, int KS, int KG = 1, int EPI = 0>
 __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1) void conv_igemm_kernel(ConvParams p) {
 #ifdef HALO_PROBE
   // tools/probe_halo.py (probe build only): with flag 0x200000 the stats pointer receives, per wave, s_memtime at [0] entry,
@@ -448,6 +452,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
   //      channel n0 + wn*WTN + j*16 + 4*(lane>>4) + r ----
   const int px = lane & 15, cq = lane >> 4;
 
+  const bool fused = KG == 1 && (p.flags & DISYOLO_CONV_BN_FUSED) != 0;
   if (p.flags & DISYOLO_CONV_STATS) {
     // per-channel sum / sum of squares of the raw f32 accumulators over this block's
     // pixels (rows past M hold exact zeros).  Deterministic: fixed shuffle tree, then a
@@ -486,9 +491,13 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
           s += red[(w_ * BN + nl) * 2 + 0];
           s2 += red[(w_ * BN + nl) * 2 + 1];
         }
-        stats_out(p, mt, n, s, s2);
+        if (fused)
+          cl_store2(p.stats + ((size_t)mt * p.Cout + n) * 2, s, s2);     // write-through: the other blocks of the cluster read it
+        else
+          stats_out(p, mt, n, s, s2);
       }
     }
+    if (fused) cl_arrive(p.csync, nt);       // (drains the stores, block barrier, one arrival)
   }
 
   if (!ep) return;
@@ -534,6 +543,101 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     constexpr int CPR8 = WTN / 8, CH = WTM * CPR8;
     bf16* yo = reinterpret_cast<bf16*>(p.y);
+    if constexpr (KG == 1 && EPI == 1) if (p.flags & DISYOLO_CONV_BN_BWD_FUSED) {
+      // ---- the target layer's whole batch-norm backward inside this data-gradient conv (DISYOLO_CONV_BN_BWD_FUSED): the
+      //      staged tile is the (now final) gradient wrt the target's ACTIVATION, rounded to bf16 as the separate launches
+      //      would have read it back.  Pass 1: this block's (sum g, sum g*xhat) per channel from the staged values and the
+      //      target's conv output -> one row of partials, exchanged within the launch (conv_common.h "cluster exchange").
+      //      Pass 2: dx = scale*g - x*A + C (bn_bwd_finalize_kernel / bn_bwd_apply_kernel, bn.hip, value for value) -> y.
+      //      The gradient wrt the activation never reaches memory; colreduce + bn_bwd_finalize + bn_bwd_apply are gone.
+      constexpr int ITERS = (CH + 63) / 64;
+      const int chl = lane % CPR8;                   // this lane's chunk column: the same in every round (64 % CPR8 == 0)
+      const int ncol = n0 + wn * WTN + chl * 8;
+      BnBwdLane bl;
+      bl.init(p, ncol, ncol < p.Cout);
+      uint4 bx[ITERS];
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int idx = it * 64 + lane;
+        const int m = m0 + wm * WTM + idx / CPR8;
+        bx[it] = (idx < CH && m < Mlim && ncol < p.Cout) ? *reinterpret_cast<const uint4*>(p.bn_x + (size_t)m * p.Cout + ncol)
+                                                          : uint4{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int idx = it * 64 + lane;
+        const int row = idx / CPR8;
+        if (idx < CH && m0 + wm * WTM + row < Mlim && ncol < p.Cout)
+          bl.add(*reinterpret_cast<const uint4*>(sw + row * ROWP + chl * 16), bx[it], p.bn_alpha);
+      }
+      bl.template reduce<CPR8>();
+      float* red = reinterpret_cast<float*>(smem);   // [WM][BN][2]: the statistics scratch (a data-gradient conv has no STATS)
+      if (lane < CPR8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          red[(wm * BN + wn * WTN + lane * 8 + k) * 2 + 0] = bl.s1[k];
+          red[(wm * BN + wn * WTN + lane * 8 + k) * 2 + 1] = bl.s2[k];
+        }
+      }
+      __syncthreads();
+      for (int nl = tid; nl < BN; nl += T) {
+        const int n = n0 + nl;
+        if (n < p.Cout) {
+          float s = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int w_ = 0; w_ < WM; ++w_) {
+            s += red[(w_ * BN + nl) * 2 + 0];
+            s2 += red[(w_ * BN + nl) * 2 + 1];
+          }
+          cl_store2(p.bn_part + ((size_t)mt * p.Cout + n) * 2, s, s2);
+        }
+      }
+      cl_arrive(p.csync, nt);
+      double* dscr = reinterpret_cast<double*>(smem + ((WM * BN * 8 + BN * 8 + NW * (WTM * ROWP) + 15) & ~15));
+      cl_wait(p.csync, nt, (unsigned)p.tilesM, ((p.Cout + 15) >> 4) * CL_LINE);
+      double r0, r1;
+      if (cl_sum_rows<T, BN>(p.bn_part, p.tilesM, p.Cout, n0, dscr, r0, r1)) {
+        const int n = n0 + tid;
+        const float sc0 = p.bn_scale[n], rs0 = p.bn_rstd[n], mean0 = p.bn_mean[n];
+        const float c1 = (float)(r0 * p.inv_count), c2 = (float)(r1 * p.inv_count);
+        const float A = sc0 * rs0 * c2;
+        scsh[tid] = A;
+        scsh[BN + tid] = mean0 * A - sc0 * c1;
+        if (mt == 0) {
+          p.dbeta[n] = (float)r0;
+          p.dgamma[n] = (float)r1;
+        }
+      }
+      __syncthreads();
+      cl_depart(p.csync, nt, (unsigned)p.tilesM);
+      float A8[8], C8[8];
+      {
+        const int nl = wn * WTN + chl * 8;
+        *reinterpret_cast<float4*>(A8) = *reinterpret_cast<const float4*>(scsh + nl);
+        *reinterpret_cast<float4*>(A8 + 4) = *reinterpret_cast<const float4*>(scsh + nl + 4);
+        *reinterpret_cast<float4*>(C8) = *reinterpret_cast<const float4*>(scsh + BN + nl);
+        *reinterpret_cast<float4*>(C8 + 4) = *reinterpret_cast<const float4*>(scsh + BN + nl + 4);
+      }
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int idx = it * 64 + lane;
+        const int row = idx / CPR8;
+        const int m = m0 + wm * WTM + row;
+        if (idx < CH && m < Mlim && ncol < p.Cout) {
+          float g[8], vx[8];
+          unpack8(*reinterpret_cast<const uint4*>(sw + row * ROWP + chl * 16), g);
+          unpack8(bx[it], vx);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float z = vx[k] * bl.sc[k] + bl.sh[k];
+            const float gg = g[k] * (z > 0.f ? 1.f : p.bn_alpha);
+            g[k] = bl.sc[k] * gg - vx[k] * A8[k] + C8[k];
+          }
+          *reinterpret_cast<uint4*>(yo + (size_t)m * p.Cout + ncol) = pack8(g);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < (CH + 63) / 64; ++it) {
       const int idx = it * 64 + lane;
@@ -541,6 +645,55 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
       const int m = m0 + wm * WTM + row, n = n0 + wn * WTN + ch * 8;
       if (idx < CH && m < Mlim && n < p.Cout)
         *reinterpret_cast<uint4*>(yo + oaddr(m, n)) = *reinterpret_cast<const uint4*>(sw + row * ROWP + ch * 16);
+    }
+    if constexpr (KG == 1 && EPI == 0) if (fused) {
+      // ---- batch norm inside the launch (DISYOLO_CONV_BN_FUSED): the conv output is on its way to y (above); now the
+      //      statistics rows of ALL pixel tiles of this channel tile -> scale / shift (every block of the cluster computes
+      //      the same bits), then the activation from the bf16 values still staged in LDS -> y_act.  What the separate
+      //      bn_finalize + bn_act_fwd launches did, without their two launch boundaries and without re-reading y.
+      double* dscr = reinterpret_cast<double*>(smem + ((WM * BN * 8 + BN * 8 + NW * (WTM * ROWP) + 15) & ~15));
+      cl_wait(p.csync, nt, (unsigned)p.tilesM, ((p.Cout + 15) >> 4) * CL_LINE);
+      double r0, r1;
+      if (cl_sum_rows<T, BN>(p.stats, p.tilesM, p.Cout, n0, dscr, r0, r1)) {
+        const int n = n0 + tid;                      // (g == 0: tid = channel of the tile)
+        float sc_, sh_, meanf, varf, rstd;
+        cl_bn_coeffs(r0, r1, p.inv_count, p.gamma[n], p.beta[n], p.bn_eps, sc_, sh_, meanf, varf, rstd);
+        scsh[tid] = sc_;
+        scsh[BN + tid] = sh_;
+        if (mt == 0) {                               // one block per channel tile keeps the layer's books
+          p.o_scale[n] = sc_;
+          p.o_shift[n] = sh_;
+          p.o_mean[n] = meanf;
+          p.o_rstd[n] = rstd;
+          if (p.mm) p.mm[n] = p.mm[n] * p.bn_decay + meanf * (1.0f - p.bn_decay);
+          if (p.mv) p.mv[n] = p.mv[n] * p.bn_decay + varf * (1.0f - p.bn_decay);
+        }
+      }
+      __syncthreads();
+      cl_depart(p.csync, nt, (unsigned)p.tilesM);
+      bf16* ya = reinterpret_cast<bf16*>(p.y_act);
+      {
+        const int chl = lane % CPR8;                 // this lane's chunk column: the same in every round (64 % CPR8 == 0)
+        const int nl = wn * WTN + chl * 8;
+        float sc8[8], sh8[8];
+        *reinterpret_cast<float4*>(sc8) = *reinterpret_cast<const float4*>(scsh + nl);
+        *reinterpret_cast<float4*>(sc8 + 4) = *reinterpret_cast<const float4*>(scsh + nl + 4);
+        *reinterpret_cast<float4*>(sh8) = *reinterpret_cast<const float4*>(scsh + BN + nl);
+        *reinterpret_cast<float4*>(sh8 + 4) = *reinterpret_cast<const float4*>(scsh + BN + nl + 4);
+#pragma unroll
+        for (int it = 0; it < (CH + 63) / 64; ++it) {
+          const int idx = it * 64 + lane;
+          const int row = idx / CPR8, ch = idx % CPR8;
+          const int m = m0 + wm * WTM + row, n = n0 + wn * WTN + ch * 8;
+          if (idx < CH && m < Mlim && n < p.Cout) {
+            float v[8];
+            unpack8(*reinterpret_cast<const uint4*>(sw + row * ROWP + ch * 16), v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = leaky(v[k] * sc8[k] + sh8[k], p.alpha);
+            *reinterpret_cast<uint4*>(ya + oaddr(m, n)) = pack8(v);
+          }
+        }
+      }
     }
     return;
   }
@@ -836,6 +989,7 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
 #ifdef DY_PROBE
   if ((p.flags & 0x80000) && acc[0][0][0] != 123.456f) return;   // timing probe: no epilogue
 #endif
+  const bool fusedf = (p.flags & DISYOLO_CONV_BN_FUSED) != 0;     // training-mode batch norm inside the launch (see the GEMM kernel)
   if (p.flags & DISYOLO_CONV_STATS) {
     float* red = reinterpret_cast<float*>(smem);  // [NW][BN][2]
 #pragma unroll
@@ -871,9 +1025,13 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
           s += red[(w_ * BN + nl) * 2 + 0];
           s2 += red[(w_ * BN + nl) * 2 + 1];
         }
-        stats_out(p, mt, n, s, s2);
+        if (fusedf)
+          cl_store2(p.stats + ((size_t)mt * p.Cout + n) * 2, s, s2);
+        else
+          stats_out(p, mt, n, s, s2);
       }
     }
+    if (fusedf) cl_arrive(p.csync, nt);
   }
 
   if (!(p.flags & DISYOLO_CONV_OUT_F32) && (p.Cout & 7) == 0) {
@@ -893,6 +1051,7 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
     // batch-norm backward sums (DISYOLO_CONV_BN_BWD_STATS): the target layer's conv output for the chunks this
     // lane will store, requested now so that the loads fly while the tile is scaled, packed and staged
     const bool bnb = p.flags & DISYOLO_CONV_BN_BWD_STATS;
+    const bool bwdf = bnb && (p.flags & DISYOLO_CONV_BN_BWD_FUSED);
     uint4 bx[FW * RPF];
     if (bnb) {
 #pragma unroll
@@ -952,7 +1111,7 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
         const int n = n0 + ch * 8;
         if (idx < 16 * CPR8 && m >= 0 && n < p.Cout) {      // (16 channels per block: the 32 chunks of a fragment fill half a round)
           const uint4 o = *reinterpret_cast<const uint4*>(sw + (t * 16 + r16) * ROWP + ch * 16);
-          *reinterpret_cast<uint4*>(yo + (size_t)m * p.Cout + n) = o;
+          if (!bwdf) *reinterpret_cast<uint4*>(yo + (size_t)m * p.Cout + n) = o;     // (fused backward: y receives dx in pass 2)
           if (bnb) bl.add(o, bx[t * RPF + it], p.bn_alpha);
         }
       }
@@ -978,7 +1137,111 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
             s += red[(w_ * BN + nl) * 2 + 0];
             s2 += red[(w_ * BN + nl) * 2 + 1];
           }
-          bnpart_out(p, mt, n, s, s2);
+          if (bwdf)
+            cl_store2(p.bn_part + ((size_t)mt * p.Cout + n) * 2, s, s2);
+          else
+            bnpart_out(p, mt, n, s, s2);
+        }
+      }
+      if (bwdf) {
+        // ---- DISYOLO_CONV_BN_BWD_FUSED (the GEMM kernel's epilogue has the commentary): exchange the rows, then pass 2
+        cl_arrive(p.csync, nt);
+        float* scsh = reinterpret_cast<float*>(smem + NW * BN * 8 + NW * (FW * 16 * ROWP));
+        double* dscr = reinterpret_cast<double*>(smem + ((NW * BN * 8 + NW * (FW * 16 * ROWP) + BN * 8 + 15) & ~15));
+        cl_wait(p.csync, nt, (unsigned)p.tilesM, ((p.Cout + 15) >> 4) * CL_LINE);
+        double r0, r1;
+        if (cl_sum_rows<NW * 64, BN>(p.bn_part, p.tilesM, p.Cout, n0, dscr, r0, r1)) {
+          const int n = n0 + tid;
+          const float sc0 = p.bn_scale[n], rs0 = p.bn_rstd[n], mean0 = p.bn_mean[n];
+          const float c1 = (float)(r0 * p.inv_count), c2 = (float)(r1 * p.inv_count);
+          const float A = sc0 * rs0 * c2;
+          scsh[tid] = A;
+          scsh[BN + tid] = mean0 * A - sc0 * c1;
+          if (mt == 0) {
+            p.dbeta[n] = (float)r0;
+            p.dgamma[n] = (float)r1;
+          }
+        }
+        __syncthreads();
+        cl_depart(p.csync, nt, (unsigned)p.tilesM);
+        float A8[8], C8[8];
+        {
+          const int nl = (lane % CPR8) * 8;
+          *reinterpret_cast<float4*>(A8) = *reinterpret_cast<const float4*>(scsh + nl);
+          *reinterpret_cast<float4*>(A8 + 4) = *reinterpret_cast<const float4*>(scsh + nl + 4);
+          *reinterpret_cast<float4*>(C8) = *reinterpret_cast<const float4*>(scsh + BN + nl);
+          *reinterpret_cast<float4*>(C8 + 4) = *reinterpret_cast<const float4*>(scsh + BN + nl + 4);
+        }
+#pragma unroll
+        for (int t = 0; t < FW; ++t) {
+#pragma unroll
+          for (int it = 0; it < RPF; ++it) {
+            const int idx = it * 64 + lane;
+            const int r16 = idx / CPR8, ch = idx % CPR8;
+            const int m = __shfl(m_of[t], r16, 64);
+            const int n = n0 + ch * 8;
+            if (idx < 16 * CPR8 && m >= 0 && n < p.Cout) {
+              float g[8], vx[8];
+              unpack8(*reinterpret_cast<const uint4*>(sw + (t * 16 + r16) * ROWP + ch * 16), g);
+              unpack8(bx[t * RPF + it], vx);
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                const float z = vx[k] * bl.sc[k] + bl.sh[k];
+                const float gg = g[k] * (z > 0.f ? 1.f : p.bn_alpha);
+                g[k] = bl.sc[k] * gg - vx[k] * A8[k] + C8[k];
+              }
+              *reinterpret_cast<uint4*>(yo + (size_t)m * p.Cout + n) = pack8(g);
+            }
+          }
+        }
+      }
+    }
+    if (fusedf) {
+      // ---- batch norm inside the launch (DISYOLO_CONV_BN_FUSED; the GEMM kernel's epilogue has the commentary): the
+      //      statistics rows of all patches of this channel tile -> scale / shift, the activation from the staged tile
+      float* scsh = reinterpret_cast<float*>(smem + NW * BN * 8 + NW * (FW * 16 * ROWP));   // [2][BN] behind the staging tiles
+      double* dscr = reinterpret_cast<double*>(smem + ((NW * BN * 8 + NW * (FW * 16 * ROWP) + BN * 8 + 15) & ~15));
+      cl_wait(p.csync, nt, (unsigned)p.tilesM, ((p.Cout + 15) >> 4) * CL_LINE);
+      double r0, r1;
+      if (cl_sum_rows<NW * 64, BN>(p.stats, p.tilesM, p.Cout, n0, dscr, r0, r1)) {
+        const int n = n0 + tid;
+        float sc_, sh_, meanf, varf, rstd;
+        cl_bn_coeffs(r0, r1, p.inv_count, p.gamma[n], p.beta[n], p.bn_eps, sc_, sh_, meanf, varf, rstd);
+        scsh[tid] = sc_;
+        scsh[BN + tid] = sh_;
+        if (mt == 0) {
+          p.o_scale[n] = sc_;
+          p.o_shift[n] = sh_;
+          p.o_mean[n] = meanf;
+          p.o_rstd[n] = rstd;
+          if (p.mm) p.mm[n] = p.mm[n] * p.bn_decay + meanf * (1.0f - p.bn_decay);
+          if (p.mv) p.mv[n] = p.mv[n] * p.bn_decay + varf * (1.0f - p.bn_decay);
+        }
+      }
+      __syncthreads();
+      cl_depart(p.csync, nt, (unsigned)p.tilesM);
+      bf16* ya = reinterpret_cast<bf16*>(p.y_act);
+      const int nl = (lane % CPR8) * 8;
+      float sc8[8], sh8[8];
+      *reinterpret_cast<float4*>(sc8) = *reinterpret_cast<const float4*>(scsh + nl);
+      *reinterpret_cast<float4*>(sc8 + 4) = *reinterpret_cast<const float4*>(scsh + nl + 4);
+      *reinterpret_cast<float4*>(sh8) = *reinterpret_cast<const float4*>(scsh + BN + nl);
+      *reinterpret_cast<float4*>(sh8 + 4) = *reinterpret_cast<const float4*>(scsh + BN + nl + 4);
+#pragma unroll
+      for (int t = 0; t < FW; ++t) {
+#pragma unroll
+        for (int it = 0; it < RPF; ++it) {
+          const int idx = it * 64 + lane;
+          const int r16 = idx / CPR8, ch = idx % CPR8;
+          const int m = __shfl(m_of[t], r16, 64);
+          const int n = n0 + ch * 8;
+          if (idx < 16 * CPR8 && m >= 0 && n < p.Cout) {
+            float v[8];
+            unpack8(*reinterpret_cast<const uint4*>(sw + (t * 16 + r16) * ROWP + ch * 16), v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = leaky(v[k] * sc8[k] + sh8[k], p.alpha);
+            *reinterpret_cast<uint4*>(ya + (size_t)m * p.Cout + n) = pack8(v);
+          }
         }
       }
     }
@@ -1678,6 +1941,33 @@ int launch_stream1x1(const ConvParams& p, hipStream_t s) {
   return launch_stream1x1_n<4>(p, s);
 }
 
+// Residency query (disyolo_conv2d_bn_fused_ok): the launchers below fill this instead of launching -- the grid, the statistics
+// rows, the channel tile and how many blocks of THIS instance the device holds at once (the cluster exchange of the fused
+// batch-norm epilogues needs every block of the launch resident: a block waits for the rows of blocks that may not have
+// started yet).
+struct LaunchQuery {
+  bool active = false, have = false, want_bwd = false, want_fused = false;
+  int grid = 0, rows = 0, bn = 0, resident = 0;
+};
+thread_local LaunchQuery tl_query;
+template <class K>
+int resident_blocks(K kernel, int threads, size_t lds) {
+  int dev = 0, cus = 0, occ = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kernel), threads, lds) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  // the occupancy API can answer one block per CU high (MI355X_MICROARCH.md "Correctness boundaries"): cap it by what LDS
+  // and the wave slots allow, whatever it says
+  const int by_lds = lds ? (int)((size_t)160 * 1024 / lds) : 8;
+  const int by_waves = 32 / (threads / 64);
+  if (occ > by_lds) occ = by_lds;
+  if (occ > by_waves) occ = by_waves;
+  return occ * cus;
+}
+
 template <int NW, int FW, int NI>
 int launch_halo(const ConvParams& p, Patch pt, hipStream_t s) {
   ConvParams q = p;
@@ -1692,14 +1982,25 @@ int launch_halo(const ConvParams& p, Patch pt, hipStream_t s) {
   constexpr int SLAB = NW * 1024, BIM = (9 * BN * 4 + NW * 64 - 1) / (NW * 64);
   // two stages (compute slice c while slice c+1 lands); a one-slice layer (32 input channels) uses the first only.
   // The epilogue's scratch (stats rows + per-wave staging tiles) must fit as well.
-  const size_t epi = (size_t)NW * BN * 8 + (size_t)NW * FW * 16 * (BN * 2 + 16);
+  const size_t epi = (size_t)NW * BN * 8 + (size_t)NW * FW * 16 * (BN * 2 + 16) + (size_t)BN * 8 + 16 + (size_t)NW * 64 * 16;   // (+ the fused batch norm's coefficients and f64 scratch)
   size_t lds = (size_t)(p.Cin > 32 ? 2 : 1) * (4 + BIM) * SLAB;
   if (lds < epi) lds = epi;
+  // (a launch whose blocks wait for each other takes whole CUs: see launch_ks)
+  if (((p.flags & (DISYOLO_CONV_BN_FUSED | DISYOLO_CONV_BN_BWD_FUSED)) || (tl_query.active && tl_query.want_fused)) && lds < (size_t)81 * 1024)
+    lds = (size_t)81 * 1024;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<NW, FW, NI>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * (4 + BIM) * SLAB));
     attr_set = true;
+  }
+  if (tl_query.active) {
+    tl_query.have = true;
+    tl_query.grid = q.tilesM * q.tilesN;
+    tl_query.rows = q.tilesM;
+    tl_query.bn = BN;
+    tl_query.resident = resident_blocks(&conv_halo_kernel<NW, FW, NI>, NW * 64, lds);
+    return DISYOLO_OK;
   }
   hipLaunchKernelGGL((conv_halo_kernel<NW, FW, NI>), dim3(q.tilesM * q.tilesN), dim3(NW * 64), lds, s, q, pt.ph,
                      pt.pw, tilesY, tilesX);
@@ -1752,13 +2053,64 @@ int launch_ks(const ConvParams& p, hipStream_t s) {
   if (red > lds) lds = red;
   const size_t xg = (size_t)(KG - 1) * BM * BN * sizeof(float);
   if (xg > lds) lds = xg;
-  const size_t stg = red + (size_t)BN * 8 + (size_t)NW * (BM / WM) * ((BN / WN) * 2 + 16);   // scale/shift + epilogue staging behind the stats scratch
+  const size_t stg = red + (size_t)BN * 8 + (size_t)NW * (BM / WM) * ((BN / WN) * 2 + 16)   // scale/shift + epilogue staging behind the stats scratch
+                     + 16 + (size_t)NW * 64 * 16;                                              // + the fused batch norm's f64 scratch
   if (stg > lds) lds = stg;
   static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
+  if (!attr_set && (lds > 64 * 1024 || KG == 1)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, ST, KS, KG>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds > (size_t)81 * 1024 ? lds : (size_t)81 * 1024));
     attr_set = true;
+  }
+  // tiles with an EPI = 1 instance (the fused batch-norm backward): what the data-gradient convs of the 18^2 / 36^2 maps run
+  constexpr bool HAS_BWD = KG == 1 && ((KS == 1 && ((BM == 64 && BN == 64) || (BM == 64 && BN == 128) || (BM == 128 && BN == 64) ||
+                                                    (BM == 96 && BN == 128) || (BM == 128 && BN == 128))) ||
+                                       (BM == 192 && BN == 128));
+  // A launch whose blocks wait for each other (the fused batch-norm epilogues) takes whole CUs: its LDS request is raised
+  // past half a CU's so that no two of its blocks share one, and disyolo_conv2d_bn_fused_ok admits it only with a grid of at
+  // most one block per CU.  Why: with several small blocks per CU a partly resident grid sits on EVERY CU; a kernel of
+  // another queue whose blocks then fit nowhere (the side lane's weight gradients: one wave per SIMD with most of its
+  // registers) stalls the workgroup dispatcher, and the rest of this grid is never placed -- measured: the 64x64-tile data
+  // gradients (656 blocks, three per CU) hung until the bounded wait gave up whenever replays ran back to back
+  // (profiles/r06_bn_inkernel.txt).  With one block per CU a CU either holds a block of this launch or is free for the
+  // other queue: the other queue always makes progress or this grid is fully resident.
+  const bool cluster = (p.flags & (DISYOLO_CONV_BN_FUSED | DISYOLO_CONV_BN_BWD_FUSED)) != 0 || (tl_query.active && tl_query.want_fused);
+  constexpr size_t EXCL_LDS = (size_t)81 * 1024;
+  if (cluster && lds < EXCL_LDS) lds = EXCL_LDS;
+  if (tl_query.active) {
+    static const bool bwd_gemm_on = [] { const char* e = getenv("DISYOLO_BN_INKERNEL_BWD_GEMM"); return !(e && e[0] == '0'); }();
+    static const bool fwd_gemm_on = [] { const char* e = getenv("DISYOLO_BN_INKERNEL_FWD_GEMM"); return !(e && e[0] == '0'); }();
+    tl_query.have = KG == 1 && q.pcls == 0 && (tl_query.want_bwd ? (HAS_BWD && bwd_gemm_on) : fwd_gemm_on);
+    tl_query.grid = grid;
+    tl_query.rows = q.tilesM;
+    tl_query.bn = BN;
+    if constexpr (HAS_BWD) {
+      if (tl_query.want_bwd) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, ST, KS, KG, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds > EXCL_LDS ? lds : EXCL_LDS));
+        tl_query.resident = resident_blocks(&conv_igemm_kernel<BM, BN, WM, WN, BK, ST, KS, KG, 1>, NW * 64 * KG, lds);
+        return DISYOLO_OK;
+      }
+    }
+    tl_query.resident = resident_blocks(&conv_igemm_kernel<BM, BN, WM, WN, BK, ST, KS, KG>, NW * 64 * KG, lds);
+    return DISYOLO_OK;
+  }
+  if (p.flags & DISYOLO_CONV_BN_BWD_FUSED) {
+    if constexpr (HAS_BWD) {
+      DY_REQUIRE(q.pcls == 0, "conv: BN_BWD_FUSED on a parity-class data gradient");
+      static bool attr1 = false;
+      if (!attr1) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, ST, KS, KG, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds > EXCL_LDS ? lds : EXCL_LDS));
+        attr1 = true;
+      }
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, ST, KS, KG, 1>), dim3(grid), dim3(NW * 64 * KG), lds, s, q);
+      DY_CHECK_LAUNCH();
+      return DISYOLO_OK;
+    } else {
+      disyolo_set_error("conv: BN_BWD_FUSED on a GEMM tile without that epilogue (%dx%d, k %d; ask disyolo_conv2d_bn_fused_ok)", BM, BN, KS);
+      return DISYOLO_E_ARG;
+    }
   }
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, ST, KS, KG>), dim3(grid), dim3(NW * 64 * KG), lds, s, q);
   DY_CHECK_LAUNCH();
@@ -2061,14 +2413,66 @@ extern "C" int disyolo_dgrad_s2_quad(const void* dy, const void* wq, void* dx, c
   return launch<192, 128, 4, 2, 64, 2>(p, (hipStream_t)stream);
 }
 
+static int conv2d_fwd_core(const disyolo_conv_desc* d, void* stream);
+
+extern "C" int disyolo_cluster_sync_words(int Cout) { return Cout > 0 ? (ceil_div(Cout, 16) + 1) * CL_LINE : 0; }
+
+extern "C" int disyolo_cluster_sync_error(const uint32_t* cluster_sync, int Cout) {
+  if (!cluster_sync || Cout <= 0) return 0;
+  uint32_t w = 0;
+  if (hipMemcpy(&w, cluster_sync + (size_t)ceil_div(Cout, 16) * CL_LINE, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return (int)w;
+}
+
+// Can this descriptor run the in-launch batch norm?  With DISYOLO_CONV_BN_BWD_FUSED in its flags the answer is for the backward
+// form (not every GEMM tile has that epilogue), otherwise for the forward form (whose flag need not be set).
+extern "C" int disyolo_conv2d_bn_fused_ok(const disyolo_conv_desc* d) {
+  if (!d || validate(d) != DISYOLO_OK) return 0;
+  if ((d->flags & DISYOLO_CONV_OUT_F32) || d->Cout % 8) return 0;     // (a residual: fine for the backward form, refused by the forward one)
+  if (d->in_div != 1 && (d->flags & (DISYOLO_CONV_STATS | DISYOLO_CONV_BN_FUSED))) return 0;
+  static const bool on = [] { const char* e = getenv("DISYOLO_BN_INKERNEL"); return !(e && e[0] == '0'); }();
+  if (!on) return 0;
+  tl_query = LaunchQuery{};
+  tl_query.active = true;
+  tl_query.want_bwd = (d->flags & DISYOLO_CONV_BN_BWD_FUSED) != 0;
+  tl_query.want_fused = true;
+  disyolo_conv_desc c = *d;
+  c.flags &= ~(DISYOLO_CONV_BN_FUSED | DISYOLO_CONV_BN_BWD_FUSED | DISYOLO_CONV_BN_BWD_STATS);
+  const int rc = conv2d_fwd_core(&c, nullptr);
+  const LaunchQuery q = tl_query;
+  tl_query = LaunchQuery{};
+  if (rc != DISYOLO_OK || !q.have) return 0;          // (a kernel without the epilogue: streaming / flat-frame forms, split-K tiles)
+  static const int max_row_kb = [] { const char* e = getenv("DISYOLO_BN_INKERNEL_ROW_KB"); return e ? atoi(e) : 128; }();
+  if ((int64_t)q.rows * q.bn * 8 > (int64_t)max_row_kb * 1024) return 0;      // every block sums all the rows of its channel tile
+  return (q.resident > 0 && q.grid <= q.resident) ? 1 : 0;
+}
+
 extern "C" int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream) {
   int rc = validate(d);
   if (rc) return rc;
   DY_REQUIRE(!(d->flags & DISYOLO_CONV_STATS) || d->stats, "conv: STATS flag without stats buffer");
+  if (d->flags & DISYOLO_CONV_BN_FUSED) {
+    DY_REQUIRE((d->flags & DISYOLO_CONV_STATS) && !(d->flags & (DISYOLO_CONV_LEAKY | DISYOLO_CONV_OUT_F32 | DISYOLO_CONV_BN_BWD_STATS)) &&
+                   !d->scale && !d->shift && !d->residual && d->Cout % 8 == 0,
+               "conv: BN_FUSED needs STATS, bf16 y, no scale / shift / LEAKY / residual (y is the raw conv output), Cout %% 8 == 0");
+    DY_REQUIRE(d->y_act && d->bn_gamma && d->bn_beta && d->bn_out_scale && d->bn_out_shift && d->bn_out_mean && d->bn_out_rstd &&
+                   d->cluster_sync, "conv: BN_FUSED with a null y_act / bn_gamma / bn_beta / bn_out_* / cluster_sync");
+  }
+  if (d->flags & DISYOLO_CONV_BN_BWD_FUSED) {
+    DY_REQUIRE((d->flags & DISYOLO_CONV_BN_BWD_STATS) && d->bn_dgamma && d->bn_dbeta && d->cluster_sync,
+               "conv: BN_BWD_FUSED needs BN_BWD_STATS (the bn_* fields) and bn_dgamma / bn_dbeta / cluster_sync");
+  }
   {
     const disyolo_conv_desc c = *d;
     DY_RECORD_OR_RUN([c](void* s) { return disyolo_conv2d_fwd(&c, s); });
   }
+  return conv2d_fwd_core(d, stream);
+}
+
+static int conv2d_fwd_core(const disyolo_conv_desc* d, void* stream) {
   ConvParams p;
   p.x0 = (const bf16*)d->x0;
   p.x1 = (const bf16*)d->x1;
@@ -2082,8 +2486,11 @@ extern "C" int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream) {
   if (d->flags & DISYOLO_CONV_BN_BWD_STATS) {
     DY_REQUIRE(d->bn_x && d->bn_scale && d->bn_shift && d->bn_mean && d->bn_rstd && d->bn_partials,
                "conv: BN_BWD_STATS flag with a null bn_* pointer");
-    DY_REQUIRE(disyolo_conv2d_bn_bwd_stats_ok(d) == 1,
+    DY_REQUIRE((d->flags & DISYOLO_CONV_BN_BWD_FUSED) || disyolo_conv2d_bn_bwd_stats_ok(d) == 1,
                "conv: BN_BWD_STATS needs a patch kernel (tile 16-18, 24, 25 on a shape it covers), bf16 output, Cout %% 8 == 0");
+    DY_REQUIRE(!(d->flags & DISYOLO_CONV_BN_BWD_FUSED) || (!(d->flags & (DISYOLO_CONV_OUT_F32 | DISYOLO_CONV_STATS | DISYOLO_CONV_LEAKY)) &&
+                                                          !d->scale && !d->shift && d->Cout % 8 == 0),
+               "conv: BN_BWD_FUSED needs a plain bf16 data-gradient conv (no scale / shift / LEAKY / STATS), Cout %% 8 == 0");
     p.bn_x = (const bf16*)d->bn_x; p.bn_scale = d->bn_scale; p.bn_shift = d->bn_shift; p.bn_mean = d->bn_mean;
     p.bn_rstd = d->bn_rstd; p.bn_part = d->bn_partials; p.bn_alpha = d->bn_alpha;
   }
@@ -2103,11 +2510,23 @@ extern "C" int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream) {
   p.xcd_n = 0;
   p.pcls = 0; p.Mc = 0; p.tilesMc = 0;
   p.tapmask = 0; p.d2s_c = 0;
+  p.y_act = d->y_act; p.gamma = d->bn_gamma; p.beta = d->bn_beta; p.mm = d->bn_moving_mean; p.mv = d->bn_moving_var;
+  p.o_scale = d->bn_out_scale; p.o_shift = d->bn_out_shift; p.o_mean = d->bn_out_mean; p.o_rstd = d->bn_out_rstd;
+  p.dgamma = d->bn_dgamma; p.dbeta = d->bn_dbeta; p.csync = d->cluster_sync;
+  p.bn_decay = d->bn_decay; p.bn_eps = d->bn_eps; p.inv_count = 1.0 / (double)p.M;
   hipStream_t s = (hipStream_t)stream;
   // tile field: low byte = tile id (0 = auto); bit 8 forces BK = 32, bit 9 selects the
   // alternative pipeline depth (tuning / testing)
   Patch pt;
   const int sel = resolve_sel(d, p.M, &pt);
+  {
+    const int id = sel & 0xff;
+    if (id == 24 || id == 25 || id == 20 || id == 21) {     // kernels without the in-launch batch-norm epilogues
+      if (tl_query.active) return DISYOLO_OK;               // (have stays false)
+      DY_REQUIRE(!(d->flags & (DISYOLO_CONV_BN_FUSED | DISYOLO_CONV_BN_BWD_FUSED)),
+                 "conv: BN_FUSED / BN_BWD_FUSED on a tile whose kernel has no such epilogue (ask disyolo_conv2d_bn_fused_ok)");
+    }
+  }
   switch (sel & 0xff) {
     case 24:
     case 25: return launch_flat(p, sel & 0xff, s);

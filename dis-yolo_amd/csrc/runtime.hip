@@ -1,6 +1,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <chrono>
+#include <functional>
+#include <mutex>
+#include <string>
 #include <utility>
 #include <vector>
 #include "common.h"
@@ -125,72 +128,138 @@ static double host_now() { return std::chrono::duration<double>(std::chrono::ste
 // blocked on an event (the chain takes 1.8-2x: the pathological case -- a side lane spends most of its life parked on
 // the main lane's events).  Which stream index is which changes with GPU_MAX_HW_QUEUES, priorities and how many streams
 // the process already has, so the lanes are CHOSEN by measurement instead of by creation order.
-static bool lane_pair_ok(hipStream_t a, hipStream_t b, double chain_alone_us) {
-  hipEvent_t ev;
-  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return true;
-  (void)hipDeviceSynchronize();
-  double t0 = host_now();
-  hipLaunchKernelGGL(lane_probe_spin_kernel, dim3(1), dim3(64), 0, a, 100 * 100LL);
-  hipLaunchKernelGGL(lane_probe_spin_kernel, dim3(1), dim3(64), 0, b, 100 * 100LL);
-  (void)hipDeviceSynchronize();
-  const double both = (host_now() - t0) * 1e6;
-  t0 = host_now();
-  for (int r = 0; r < 20; ++r) hipLaunchKernelGGL(lane_probe_spin_kernel, dim3(1), dim3(64), 0, a, 10 * 100LL);
-  (void)hipEventRecord(ev, a);
-  (void)hipStreamWaitEvent(b, ev, 0);
-  hipLaunchKernelGGL(lane_probe_spin_kernel, dim3(1), dim3(64), 0, b, 10 * 100LL);
-  (void)hipDeviceSynchronize();
-  const double chain = (host_now() - t0) * 1e6;
-  (void)hipEventDestroy(ev);
-  static const bool verbose = getenv("DISYOLO_LANE_PROBE") && getenv("DISYOLO_LANE_PROBE")[0] == '2';
-  if (verbose) fprintf(stderr, "[lane probe] %p beside %p: two 100-us kernels %.0f us, chain %.0f us (alone %.0f)\n", (void*)b, (void*)a, both, chain, chain_alone_us);
-  return both < 170.0 && chain < 1.45 * chain_alone_us + 15.0;
-}
-static double lane_chain_alone(hipStream_t a) {
+// Every threshold is RELATIVE to a time measured in the same call, and every measurement is the minimum of several repeats
+// (round 5 compared host wall-clock times with absolute bounds: under a profiler, a loaded host or another thread's GPU
+// work every candidate failed them and the fallback could be exactly the queue-sharing stream that costs 2.5x):
+//   single = one 100-us spin kernel on `a`, launch to completion;  both = one on `a` and one on `b` at once
+//     -> beside each other: both ~ single; one hardware queue: both ~ 2 single.  Pass: both < 1.5 single.
+//   chain_alone = 21 x 10-us kernels on `a`;  chain = 20 on `a`, `b` parked on an event behind them, 1 on `b`
+//     -> pass: chain < 1.45 chain_alone (a neighbour that stalls the stream it is parked on takes 1.8-2x).
+struct LaneProbe {
+  double single_us = 0, both_us = 0, chain_us = 0, chain_alone_us = 0;
+  bool ok = false;
+};
+static double timed_min(int repeats, const std::function<void()>& enqueue) {
   double best = 1e30;
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < repeats; ++k) {
     (void)hipDeviceSynchronize();
     const double t0 = host_now();
-    for (int r = 0; r < 21; ++r) hipLaunchKernelGGL(lane_probe_spin_kernel, dim3(1), dim3(64), 0, a, 10 * 100LL);
+    enqueue();
     (void)hipDeviceSynchronize();
     const double t = (host_now() - t0) * 1e6;
     if (t < best) best = t;
   }
   return best;
 }
+static double lane_chain_alone(hipStream_t a) {
+  return timed_min(3, [&] {
+    for (int r = 0; r < 21; ++r) hipLaunchKernelGGL(lane_probe_spin_kernel, dim3(1), dim3(64), 0, a, 10 * 100LL);
+  });
+}
+static LaneProbe lane_pair_probe(hipStream_t a, hipStream_t b, double chain_alone_us) {
+  LaneProbe r;
+  r.chain_alone_us = chain_alone_us;
+  hipEvent_t ev;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+    r.ok = true;
+    return r;
+  }
+  r.single_us = timed_min(3, [&] { hipLaunchKernelGGL(lane_probe_spin_kernel, dim3(1), dim3(64), 0, a, 100 * 100LL); });
+  r.both_us = timed_min(3, [&] {
+    hipLaunchKernelGGL(lane_probe_spin_kernel, dim3(1), dim3(64), 0, a, 100 * 100LL);
+    hipLaunchKernelGGL(lane_probe_spin_kernel, dim3(1), dim3(64), 0, b, 100 * 100LL);
+  });
+  r.chain_us = timed_min(3, [&] {
+    for (int k = 0; k < 20; ++k) hipLaunchKernelGGL(lane_probe_spin_kernel, dim3(1), dim3(64), 0, a, 10 * 100LL);
+    (void)hipEventRecord(ev, a);
+    (void)hipStreamWaitEvent(b, ev, 0);
+    hipLaunchKernelGGL(lane_probe_spin_kernel, dim3(1), dim3(64), 0, b, 10 * 100LL);
+  });
+  (void)hipEventDestroy(ev);
+  r.ok = r.both_us < 1.5 * r.single_us && r.chain_us < 1.45 * r.chain_alone_us;
+  static const bool verbose = getenv("DISYOLO_LANE_PROBE") && getenv("DISYOLO_LANE_PROBE")[0] == '2';
+  if (verbose)
+    fprintf(stderr, "[lane probe] %p beside %p: single %.0f us, two at once %.0f us, chain %.0f us (alone %.0f): %s\n", (void*)b, (void*)a,
+            r.single_us, r.both_us, r.chain_us, r.chain_alone_us, r.ok ? "ok" : "rejected");
+  return r;
+}
 #endif
-static bool pool_lane(int i) {
+// what the pool did, per device and lane, for the bench line (disyolo_lanes_report): a slow run can be attributed
+struct LaneChoice {
+  int candidates = 0;        // streams created until one passed
+  bool probed = false, fallback = false;
+  double single_us = 0, both_us = 0, chain_us = 0, chain_alone_us = 0;     // the accepted (or last) candidate against the null stream
+  int priority = 0;
+};
+static LaneChoice g_choice[MAXDEV][NLANES];
+static std::mutex g_pool_mu;      // (the recorder state is thread-local, the pool is not)
+static bool pool_lane(int i, hipStream_t caller = nullptr) {
   if (i <= 0 || i >= NLANES) return false;
+  std::lock_guard<std::mutex> lock(g_pool_mu);
   hipStream_t* g_pool = cur_pool();
   if (g_pool[i]) return true;
+  int devi = 0;
+  if (hipGetDevice(&devi) != hipSuccess || devi < 0 || devi >= MAXDEV) devi = 0;
+  LaneChoice& rep = g_choice[devi][i];
   int least = 0, greatest = 0;
   const char* l1 = getenv("DISYOLO_LANE1_LOW");
   const bool lane1_low = !(l1 && l1[0] == '0');
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;   // no device (CPU-only build check)
   const bool low = (i == 2 && getenv("DISYOLO_LANE2_LOW")) || (i == 1 && lane1_low) || (i == 3 && !(getenv("DISYOLO_LANE3_LOW") && getenv("DISYOLO_LANE3_LOW")[0] == '0'));
   const int prio = low ? least : 0;
+  rep.priority = prio;
 #ifndef DY_HOST_ONLY
   const char* pe = getenv("DISYOLO_LANE_PROBE");
-  if (!(pe && pe[0] == '0')) {
+  bool probe = !(pe && pe[0] == '0');
+  if (probe) {
+    // the probe synchronises the device and launches on the null stream: illegal while a stream capture is active
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (caller && hipStreamIsCapturing(caller, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+      fprintf(stderr, "disyolo: lane %d is created while a stream capture is active: NOT probed (first stream taken; create the lanes before "
+                      "capturing: disyolo_lanes_reserve)\n", i);
+      probe = false;
+    }
+    (void)hipGetLastError();
+    // (no stream in hand -- a lane first used while a list is being recorded: a device synchronise fails under any active
+    //  capture, and then nothing below may run)
+    if (probe && hipDeviceSynchronize() != hipSuccess) {
+      (void)hipGetLastError();
+      fprintf(stderr, "disyolo: lane %d: the device cannot be synchronised here (a stream capture is active?): NOT probed, first stream taken\n", i);
+      probe = false;
+    }
+  }
+  if (probe) {
     // candidates in creation order until one runs beside the caller's (null) stream and beside the lanes that exist, in both
     // roles; the rejected ones are released afterwards.  DISYOLO_LANE_PROBE=0: the first stream, unmeasured; =2: verbose
     hipStream_t rejected[16];
     int nrej = 0;
     hipStream_t pick = nullptr;
     const double alone0 = lane_chain_alone(nullptr);
+    LaneProbe last;
     while (nrej < 16) {
       hipStream_t c = nullptr;
       if (hipStreamCreateWithPriority(&c, hipStreamNonBlocking, prio) != hipSuccess) break;
-      bool ok = lane_pair_ok(nullptr, c, alone0) && lane_pair_ok(c, nullptr, lane_chain_alone(c));
+      ++rep.candidates;
+      last = lane_pair_probe(nullptr, c, alone0);
+      bool ok = last.ok && lane_pair_probe(c, nullptr, lane_chain_alone(c)).ok;
       for (int j = 1; j < NLANES && ok; ++j)
-        if (g_pool[j]) ok = lane_pair_ok(g_pool[j], c, lane_chain_alone(g_pool[j])) && lane_pair_ok(c, g_pool[j], lane_chain_alone(c));
+        if (g_pool[j]) ok = lane_pair_probe(g_pool[j], c, lane_chain_alone(g_pool[j])).ok && lane_pair_probe(c, g_pool[j], lane_chain_alone(c)).ok;
       if (ok) {
         pick = c;
         break;
       }
       rejected[nrej++] = c;
     }
-    if (!pick && nrej > 0) pick = rejected[--nrej];      // nothing passed: the last candidate (the step still runs)
+    rep.probed = true;
+    rep.single_us = last.single_us; rep.both_us = last.both_us; rep.chain_us = last.chain_us; rep.chain_alone_us = last.chain_alone_us;
+    if (!pick && nrej > 0) {
+      pick = rejected[--nrej];      // nothing passed: the last candidate (the step still runs) -- and say so
+      rep.fallback = true;
+      fprintf(stderr, "disyolo: lane %d: none of %d candidate streams ran cleanly beside the caller's stream (last: two 100-us kernels at once "
+                      "%.0f us against %.0f alone, chain %.0f us against %.0f alone); keeping the last one -- the step may be serialised or "
+                      "stalled by this lane (DISYOLO_LANE_PROBE=2 prints every candidate)\n", i, rep.candidates, last.both_us, last.single_us,
+              last.chain_us, last.chain_alone_us);
+    }
     for (int k = 0; k < nrej; ++k) (void)hipStreamDestroy(rejected[k]);
     (void)hipGetLastError();
     if (pick) {
@@ -204,7 +273,28 @@ static bool pool_lane(int i) {
     g_pool[i] = nullptr;
     return false;
   }
+  rep.candidates = 1;
   return true;
+}
+// one line per lane of the current device that exists: how it was chosen (bench.py puts it into config.box)
+extern "C" int disyolo_lanes_report(char* buf, int size) {
+  if (!buf || size <= 0) return DISYOLO_E_ARG;
+  int devi = 0;
+  if (hipGetDevice(&devi) != hipSuccess || devi < 0 || devi >= MAXDEV) devi = 0;
+  (void)hipGetLastError();
+  std::string out;
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  for (int i = 1; i < NLANES; ++i) {
+    if (!g_pool_dev[devi][i]) continue;
+    const LaneChoice& r = g_choice[devi][i];
+    char line[256];
+    snprintf(line, sizeof line, "lane %d: priority %d, %s, candidates %d%s, single %.0f us, two at once %.0f us, chain %.0f us (alone %.0f)\n", i,
+             r.priority, r.probed ? "probed" : "unprobed", r.candidates, r.fallback ? ", FALLBACK (none passed)" : "", r.single_us, r.both_us,
+             r.chain_us, r.chain_alone_us);
+    out += line;
+  }
+  snprintf(buf, (size_t)size, "%s", out.c_str());
+  return DISYOLO_OK;
 }
 static bool ensure_lane(CmdList* c, int i) {
   if (i <= 0 || i >= NLANES) return i == 0;

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("DISYOLO_LIB", os.path.join(_HERE, "libdisyolo_hip.so"
 GRAD_LD = 32
 ROI_MAX = 16
 ROI_W = 12
-CONV_LEAKY, CONV_OUT_F32, CONV_STATS, CONV_BN_BWD_STATS = 1, 2, 4, 8
+CONV_LEAKY, CONV_OUT_F32, CONV_STATS, CONV_BN_BWD_STATS, CONV_BN_FUSED, CONV_BN_BWD_FUSED = 1, 2, 4, 8, 16, 32
 
 
 class DisyoloError(RuntimeError):
@@ -40,6 +40,11 @@ class ConvDesc(C.Structure):
         ("y", C.c_void_p), ("stats", C.c_void_p),
         ("bn_x", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("bn_mean", C.c_void_p),
         ("bn_rstd", C.c_void_p), ("bn_partials", C.c_void_p), ("bn_alpha", C.c_float),
+        ("bn_decay", C.c_float), ("bn_eps", C.c_float),
+        ("y_act", C.c_void_p), ("bn_gamma", C.c_void_p), ("bn_beta", C.c_void_p),
+        ("bn_moving_mean", C.c_void_p), ("bn_moving_var", C.c_void_p),
+        ("bn_out_scale", C.c_void_p), ("bn_out_shift", C.c_void_p), ("bn_out_mean", C.c_void_p), ("bn_out_rstd", C.c_void_p),
+        ("bn_dgamma", C.c_void_p), ("bn_dbeta", C.c_void_p), ("cluster_sync", C.c_void_p),
     ]
 
 
@@ -51,6 +56,9 @@ _SIGS = {
                                         C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "disyolo_conv2d_stats_rows": (C.c_int, [C.POINTER(ConvDesc)]),
     "disyolo_conv2d_bn_bwd_stats_ok": (C.c_int, [C.POINTER(ConvDesc)]),
+    "disyolo_conv2d_bn_fused_ok": (C.c_int, [C.POINTER(ConvDesc)]),
+    "disyolo_cluster_sync_words": (C.c_int, [C.c_int]),
+    "disyolo_cluster_sync_error": (C.c_int, [C.c_void_p, C.c_int]),
     "disyolo_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "disyolo_conv2d_tile": (C.c_int, [C.POINTER(ConvDesc)] + [C.POINTER(C.c_int)] * 4),
     "disyolo_conv_first_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
@@ -153,6 +161,7 @@ _SIGS = {
     "disyolo_cmdlist_side_stream": (C.c_void_p, [C.c_void_p]),
     "disyolo_cmdlist_lane_stream": (C.c_void_p, [C.c_void_p, C.c_int]),
     "disyolo_lanes_reserve": (C.c_int, [C.c_int]),
+    "disyolo_lanes_report": (C.c_int, [C.c_char_p, C.c_int]),
     "disyolo_comm_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "disyolo_comm_unique_id": (C.c_int, [C.c_void_p]),
     "disyolo_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -312,10 +321,15 @@ def same_pads(size: int, k: int, s: int):
 
 def make_conv_desc(x0, w_packed, y, ksize, stride, *, x1=None, scale=None, shift=None, residual=None, stats=None,
                    leaky=False, out_f32=False, alpha=0.1, tile=0, in_div=1, pads=None, out_hw=None,
-                   bn_bwd=None) -> ConvDesc:
+                   bn_bwd=None, bn_fused=None, bn_bwd_fused=None) -> ConvDesc:
     """``bn_bwd`` = (x, scale, shift, mean, rstd, partials, alpha) of the batch-normalised layer whose output
     gradient ``y`` becomes final with this conv: its batch-norm backward sums are emitted by the epilogue (only the
-    3x3 patch kernel can: check ``conv2d_bn_bwd_stats_ok`` on the descriptor without it first)"""
+    3x3 patch kernel can: check ``conv2d_bn_bwd_stats_ok`` on the descriptor without it first).
+    ``bn_fused`` = dict(y_act, gamma, beta, mm, mv, scale, shift, mean, rstd, decay, eps, sync): training-mode batch norm
+    inside the launch (DISYOLO_CONV_BN_FUSED; ``stats`` must be given, ``y`` receives the raw conv output, ``y_act`` the
+    activation; check ``conv2d_bn_fused_ok`` on a descriptor without it first).
+    ``bn_bwd_fused`` = dict(dgamma, dbeta, sync) on top of ``bn_bwd``: the target's whole batch-norm backward inside this
+    data-gradient conv (``y`` receives dx of the target's conv output)."""
     B, H, W, C0 = x0.shape
     C1 = 0 if x1 is None else x1.shape[3]
     if out_hw is None:
@@ -341,9 +355,40 @@ def make_conv_desc(x0, w_packed, y, ksize, stride, *, x1=None, scale=None, shift
         d.flags |= CONV_BN_BWD_STATS
         d.bn_x, d.bn_scale, d.bn_shift, d.bn_mean, d.bn_rstd, d.bn_partials = (_p(t) for t in bn_bwd[:6])
         d.bn_alpha = bn_bwd[6]
+    if bn_fused is not None:
+        f = bn_fused
+        if stats is None or leaky or scale is not None or shift is not None or residual is not None:
+            raise DisyoloError("make_conv_desc(bn_fused=...): needs stats, and no scale / shift / leaky / residual")
+        d.flags |= CONV_BN_FUSED
+        d.y_act, d.bn_gamma, d.bn_beta = _p(f["y_act"]), _p(f["gamma"]), _p(f["beta"])
+        d.bn_moving_mean, d.bn_moving_var = _p(f.get("mm")), _p(f.get("mv"))
+        d.bn_out_scale, d.bn_out_shift, d.bn_out_mean, d.bn_out_rstd = _p(f["scale"]), _p(f["shift"]), _p(f["mean"]), _p(f["rstd"])
+        d.bn_decay, d.bn_eps = f["decay"], f["eps"]
+        d.cluster_sync = _p(f["sync"])
+    if bn_bwd_fused is not None:
+        f = bn_bwd_fused
+        if bn_bwd is None:
+            raise DisyoloError("make_conv_desc(bn_bwd_fused=...): needs bn_bwd")
+        d.flags |= CONV_BN_BWD_FUSED
+        d.bn_dgamma, d.bn_dbeta, d.cluster_sync = _p(f["dgamma"]), _p(f["dbeta"]), _p(f["sync"])
     # the struct only holds raw pointers: keep the tensors alive as long as the descriptor
-    d._keepalive = (x0, x1, w_packed, scale, shift, residual, y, stats, bn_bwd)
+    d._keepalive = (x0, x1, w_packed, scale, shift, residual, y, stats, bn_bwd, bn_fused, bn_bwd_fused)
     return d
+
+
+def conv2d_bn_fused_ok(d: ConvDesc) -> bool:
+    """can this descriptor (its shape and tile) run batch norm inside the launch -- a kernel with the epilogue and a grid
+    that is resident at once on this device?  (make_conv_desc(bn_fused=...) / (bn_bwd_fused=...))"""
+    return load().disyolo_conv2d_bn_fused_ok(C.byref(d)) == 1
+
+
+def cluster_sync_buffer(cout: int, device) -> torch.Tensor:
+    """the counters of one layer's in-launch exchange (zeroed once; the launches leave them zero) + its error word"""
+    return torch.zeros(load().disyolo_cluster_sync_words(cout), dtype=torch.int32, device=device)
+
+
+def cluster_sync_error(buf: torch.Tensor, cout: int) -> int:
+    return load().disyolo_cluster_sync_error(_p(buf), cout)
 
 
 def conv2d_bn_bwd_stats_ok(d: ConvDesc) -> bool:
@@ -398,12 +443,17 @@ class ConvTuner:
             # the number of batch-norm partial-sum rows depends on the tile: the finalize that follows must sum
             # exactly the rows THIS candidate writes, or the tuning passes run on garbage statistics
             self.stats_rows[d.stats] = conv2d_stats_rows(d)
+        # a candidate tile may have no in-launch batch-norm epilogue, or a grid that is not resident at once: the tuning
+        # passes run every conv without it (the caller issues the separate batch-norm launches while a tuner is active)
+        keep_flags = d.flags
+        d.flags &= ~(CONV_BN_FUSED | CONV_BN_BWD_FUSED)
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
         rc = load().disyolo_conv2d_fwd(C.byref(d), _stream())
         e.record()
         d.tile = keep
+        d.flags = keep_flags
         _check(rc, "conv2d_fwd")
         if self.covers[ck]:
             self.events.setdefault(ck, []).append((s, e))
@@ -1052,6 +1102,13 @@ def reserve_lanes(lanes=(1, COMM_LANE)) -> None:
     for i in lanes:
         mask |= 1 << int(i)
     _check(load().disyolo_lanes_reserve(mask), "lanes_reserve")
+
+
+def lanes_report() -> list:
+    """how the side lanes that exist on the current device were chosen (csrc/runtime.hip pool_lane): one string per lane"""
+    buf = C.create_string_buffer(2048)
+    _check(load().disyolo_lanes_report(buf, len(buf)), "lanes_report")
+    return [ln for ln in buf.value.decode().splitlines() if ln]
 
 
 def rccl_path() -> Optional[str]:

@@ -36,7 +36,8 @@ class Layer:
                  "Wo", "w", "bias", "gamma", "beta", "mm", "mv", "scale", "shift", "mean", "rstd", "wp", "wdg", "raw",
                  "act", "stats", "stats_rows", "desc", "grad", "grad_set", "need_grad", "dw", "dbias", "dgamma",
                  "dbeta", "dx", "pad_t", "pad_l", "dgrad_descs", "wgrad_desc", "cout_pad",
-                 "act8", "w8", "s_w", "s_out", "escale", "desc8", "dual16", "bn_sums", "bwd_local", "bwd_global", "bwd_part", "bwd_part_rows", "wq")
+                 "act8", "w8", "s_w", "s_out", "escale", "desc8", "dual16", "bn_sums", "bwd_local", "bwd_global", "bwd_part", "bwd_part_rows", "wq",
+                 "csync", "fused_fwd", "csync_bwd", "fused_bwd")
 
     def __init__(self, idx, cin, cout, k, stride, kind, src, src_up=None, shortcut=None):
         self.idx, self.cin, self.cout, self.k, self.stride, self.kind = idx, cin, cout, k, stride, kind
@@ -192,6 +193,17 @@ class YOLONet(object):
         self.fuse_first_two = os.environ.get("DISYOLO_FUSE12", "1") != "0"
         self.fuse_blocks = os.environ.get("DISYOLO_FUSE_BLOCKS", "1") != "0"
         self.use_side_lane = os.environ.get("DISYOLO_SIDE_LANE", "1") != "0"
+        # training-mode batch norm INSIDE the conv launches of the main lane (DISYOLO_CONV_BN_FUSED, csrc/conv_common.h
+        # "cluster exchange"): wherever a trainable layer's whole grid is resident at once, its bn_finalize + bn_act_fwd
+        # launches (forward) disappear into the conv's epilogue.  Off: DISYOLO_BN_INKERNEL=0, or bn_inkernel = False before
+        # the descriptors are (re)built.  Never on the side lane's layers: two such launches must not run concurrently.
+        self.bn_inkernel = os.environ.get("DISYOLO_BN_INKERNEL", "1") != "0"
+        # ... and the backward form (DISYOLO_CONV_BN_BWD_FUSED): the data-gradient conv that makes a layer's output gradient
+        # final runs that layer's whole batch-norm backward in its epilogue (colreduce + bn_bwd_finalize + bn_bwd_apply gone)
+        # Built, parity-green, measured and left OFF (DISYOLO_BN_INKERNEL_BWD=1 turns it on): with the side lane's weight
+        # gradients beside it the backward pass is bound by what the two lanes' kernels take from the CUs, not by the main
+        # lane's launch count -- 14 layers x 3 launches fewer changed the step by -1.2 ... +0.2 % (profiles/r06_bn_inkernel.txt)
+        self.bn_inkernel_bwd = os.environ.get("DISYOLO_BN_INKERNEL_BWD", "0") == "1"
         # debug mode of the fused batch-norm backward (set to a list): every layer whose backward sums come from the
         # data-gradient conv's epilogue ALSO runs the plain column reduction on the same gradient (eager steps only) and
         # appends the relative differences of dx / dgamma / dbeta
@@ -544,11 +556,58 @@ class YOLONet(object):
                     l.stats_rows = L.conv2d_stats_rows(d0)
                     l.stats = torch.zeros(l.stats_rows, l.cout, 2, dtype=F32, device=dev)
                 l.desc = L.make_conv_desc(x0, l.wp, l.raw, l.k, l.stride, x1=x1, stats=l.stats)
+                l.fused_fwd = False
+                if (self.bn_inkernel and not self.sync_bn and res is None and l.idx not in self.HEAD_LAYERS
+                        and not getattr(self, "plan_only", False) and l.stride == 1):
+                    # the tile: the table's if its grid can run the in-launch exchange (one block per CU, all resident),
+                    # else the covering tile with the largest such grid (the statistics buffer follows the tile's rows)
+                    tile = self._fused_tile(lambda t: L.make_conv_desc(x0, l.wp, l.raw, l.k, l.stride, x1=x1, tile=t), l.k)
+                    if tile is not None:
+                        d0 = L.make_conv_desc(x0, l.wp, l.raw, l.k, l.stride, x1=x1, tile=tile)
+                        rows = L.conv2d_stats_rows(d0)
+                        l.stats_rows = rows
+                        if l.stats.shape[0] < rows:      # (never shrunk: autotune() sizes it for every candidate's rows)
+                            l.stats = torch.zeros(rows, l.cout, 2, dtype=F32, device=dev)
+                        if l.csync is None:
+                            l.csync = L.cluster_sync_buffer(l.cout, dev)
+                        l.desc = L.make_conv_desc(x0, l.wp, l.raw, l.k, l.stride, x1=x1, stats=l.stats, tile=tile,
+                                                  bn_fused=dict(y_act=l.act, gamma=l.gamma, beta=l.beta, mm=l.mm, mv=l.mv,
+                                                                scale=l.scale, shift=l.shift, mean=l.mean, rstd=l.rstd,
+                                                                decay=cfg.BN_DECAY, eps=cfg.BN_EPSILON, sync=l.csync),
+                                                  alpha=cfg.ALPHA)
+                        l.fused_fwd = True
             else:
                 l.desc = L.make_conv_desc(x0, l.wp, l.act, l.k, l.stride, x1=x1, scale=l.scale, shift=l.shift,
                                           residual=res, leaky=True, alpha=cfg.ALPHA)
             if self.training and not l.lock:
                 l.wgrad_desc = L.make_conv_desc(x0, l.wp, l.act, l.k, l.stride, x1=x1)
+
+    # tiles tried for a launch that runs batch norm in its epilogue when the table's own cannot (its grid must be one block
+    # per CU at most): GEMM tiles 64x128, 128x64, 64x64, 96x128, 128x128, 192x128; for 3x3 layers the patch kernels first
+    FUSED_TILES_1x1 = (3, 2, 6, 10, 1, 12, 0x20c)
+    FUSED_TILES_3x3 = (16, 18, 19, 12, 0x20c)
+
+    def _fused_tile(self, make_desc, k: int, bwd: bool = False):
+        """tile code for a conv that carries the in-launch batch norm (forward form, or backward with ``bwd``), or None.
+        ``make_desc(tile)`` builds the plain descriptor (tile 0 = the table's / launcher's pick)."""
+        best, best_blocks = None, -1
+        for i, t in enumerate((0,) + (self.FUSED_TILES_3x3 if k == 3 else self.FUSED_TILES_1x1)):
+            d = make_desc(t)
+            tid, bm, bn, _, _ = L.conv2d_tile(d)
+            if t and tid != (t & 0xff):
+                continue                      # (the candidate does not cover the shape: the launcher fell back)
+            if bwd:
+                d.flags |= L.CONV_BN_BWD_FUSED
+            ok = L.conv2d_bn_fused_ok(d)
+            d.flags &= ~L.CONV_BN_BWD_FUSED
+            if not ok:
+                continue
+            if i == 0:
+                return d.tile                 # the table's own tile runs it: keep it
+            blocks = L.conv2d_stats_rows(d) * (-(-d.Cout // bn))
+            if blocks > best_blocks:
+                best, best_blocks = t, blocks
+        return best
 
     def _input_of(self, l, src: int) -> torch.Tensor:
         """activation of layer ``src`` as layer ``l`` reads it (backbone_pair: a trainable layer sees the current half of
@@ -811,6 +870,8 @@ class YOLONet(object):
             L.conv2d_fwd(l.desc)
         elif train_bn:
             L.conv2d_fwd(l.desc)                       # raw conv + per-channel partial sums
+            if l.fused_fwd and L.TUNER is None:
+                return                                 # ... and, in the same launch, the statistics, the moving averages and the activation
             self._bn_finalize(l, M)
             L.bn_act_fwd(l.raw, l.scale, l.shift, res, l.act, M, l.cout, cfg.ALPHA)
         else:
@@ -1077,7 +1138,13 @@ class YOLONet(object):
         res = None if (first or "tmp" in desc_kw) else tgt.grad
         d = L.make_conv_desc(dx, desc_kw["w"], out, k, 1, in_div=in_div, pads=desc_kw["pads"], out_hw=desc_kw["out_hw"],
                              residual=res)
-        if final and L.TUNER is None and L.conv2d_bn_bwd_stats_ok(d):     # (the tuner swaps tiles under the descriptor)
+        whole, tile_f = False, None
+        if (final and L.TUNER is None and self.bn_inkernel and self.bn_inkernel_bwd and not self.sync_bn
+                and self.bn_fuse_check is None and not self._shortcut_feeds_grad(tgt) and in_div == 1):
+            tile_f = self._fused_tile(lambda t: L.make_conv_desc(dx, desc_kw["w"], out, k, 1, in_div=in_div, pads=desc_kw["pads"],
+                                                                 out_hw=desc_kw["out_hw"], residual=res, tile=t), k, bwd=True)
+            whole = tile_f is not None
+        if final and L.TUNER is None and not whole and L.conv2d_bn_bwd_stats_ok(d):     # (the tuner swaps tiles under the descriptor)
             rows = L.conv2d_stats_rows(d)
             need = rows * tgt.cout * 2
             if tgt.bwd_part is None or tgt.bwd_part.numel() < need:
@@ -1086,7 +1153,28 @@ class YOLONet(object):
             d = L.make_conv_desc(dx, desc_kw["w"], out, k, 1, in_div=in_div, pads=desc_kw["pads"], out_hw=desc_kw["out_hw"],
                                  residual=res,
                                  bn_bwd=(tgt.raw, tgt.scale, tgt.shift, tgt.mean, tgt.rstd, tgt.bwd_part, cfg.ALPHA))
+        elif whole:
+            # the target's WHOLE batch-norm backward inside this conv (DISYOLO_CONV_BN_BWD_FUSED): the sums are exchanged
+            # within the launch and the conv writes tgt.dx; backward() then skips tgt's three batch-norm launches
+            d = L.make_conv_desc(dx, desc_kw["w"], out, k, 1, in_div=in_div, pads=desc_kw["pads"], out_hw=desc_kw["out_hw"],
+                                 residual=res, tile=tile_f)
+            rows = L.conv2d_stats_rows(d)
+            need = rows * tgt.cout * 2
+            if tgt.bwd_part is None or tgt.bwd_part.numel() < need:
+                tgt.bwd_part = torch.empty(need, dtype=torch.float32, device=self.device)
+            if tgt.csync_bwd is None:
+                tgt.csync_bwd = L.cluster_sync_buffer(tgt.cout, self.device)
+            d = L.make_conv_desc(dx, desc_kw["w"], tgt.dx, k, 1, in_div=in_div, pads=desc_kw["pads"], out_hw=desc_kw["out_hw"],
+                                 residual=res, tile=tile_f,
+                                 bn_bwd=(tgt.raw, tgt.scale, tgt.shift, tgt.mean, tgt.rstd, tgt.bwd_part, cfg.ALPHA),
+                                 bn_bwd_fused=dict(dgamma=tgt.dgamma, dbeta=tgt.dbeta, sync=tgt.csync_bwd))
+            tgt.fused_bwd = True
         L.conv2d_fwd(d)
+
+    def _shortcut_feeds_grad(self, tgt: Layer) -> bool:
+        """tgt is a residual layer whose output gradient also goes to its shortcut's source (res_conv_bn): that copy rides
+        on the separate batch-norm backward's apply pass"""
+        return tgt.shortcut is not None and self.by_idx[tgt.shortcut].grad is not None
 
     def _final_writers(self, visit) -> Dict[int, Tuple[int, str]]:
         """layer idx -> (idx of the layer whose backward makes its output gradient final, how: "direct" = a
@@ -1126,6 +1214,7 @@ class YOLONet(object):
         final_of = self._final_writers(visit) if fuse_bn else {}
         for l in self.layers:
             l.bwd_part_rows = 0
+            l.fused_bwd = False
         # (data parallelism with a cut list: the sweep must follow the bucket's all-reduce -- it stays in optimizer_step;
         # with the exchange in the list the slice's all-reduce and its sweep go to the exchange lane together)
         inl = self.dp is not None and self.dp.inlist
@@ -1236,7 +1325,9 @@ class YOLONet(object):
                     sc = None
                 fuse_sc = sc is not None and os.environ.get("DISYOLO_SHORTCUT_FUSE", "1") != "0"
                 kw = dict(shortcut_grad=sc.grad, shortcut_accumulate=sc.grad_set) if fuse_sc else {}
-                if self.sync_bn:
+                if l.fused_bwd:
+                    pass        # l.dx, l.dgamma, l.dbeta came out of the data-gradient conv that made l.grad final (_accumulate_into)
+                elif self.sync_bn:
                     # (sum g, sum g*xhat) of this rank -> the same over all ranks -> dx; dgamma / dbeta stay local
                     L.bn_bwd_reduce(l.grad, l.raw, l.scale, l.shift, l.mean, l.rstd, M, l.cout, l.bwd_local, self.ws, cfg.ALPHA)
                     L.copy2d_f32(l.bwd_local.view(torch.float32), l.bwd_global.view(torch.float32), 1, 4 * l.cout,

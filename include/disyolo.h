@@ -58,6 +58,28 @@ enum {
                                    3x3 patch kernels have this epilogue (tile ids 16-18, 24,
                                    25: disyolo_conv2d_bn_bwd_stats_ok tells), bf16 y,
                                    Cout % 8 == 0 (TF autodiff of :68-107)                */
+  DISYOLO_CONV_BN_FUSED = 16,   /* with DISYOLO_CONV_STATS: training-mode batch norm INSIDE the launch
+                                   (tf.nn.moments + batch_normalization + the moving-average assigns +
+                                   leaky_relu, :90-107, in the conv's epilogue).  The blocks that share a
+                                   channel tile exchange their statistics rows through `stats` within the
+                                   launch (write-through stores, an arrival counter in `cluster_sync`,
+                                   every block sums the rows in the same fixed order), then write BOTH
+                                   y = the conv output (bf16, what the backward pass keeps) and y_act =
+                                   leaky(y*scale + shift) computed from the bf16-rounded y -- bit for bit
+                                   what disyolo_bn_finalize + disyolo_bn_act_fwd produce from y (up to the
+                                   f64 summation order of the statistics rows) -- and one block per channel
+                                   tile writes bn_out_* and updates the moving statistics.  Needs every
+                                   block of the launch resident at once: disyolo_conv2d_bn_fused_ok tells;
+                                   never run two such launches concurrently on one device (each waits for
+                                   its own blocks: with both half-resident neither completes; the wait is
+                                   bounded and reports through disyolo_cluster_sync_error)             */
+  DISYOLO_CONV_BN_BWD_FUSED = 32,/* with the bn_* fields of DISYOLO_CONV_BN_BWD_STATS: the whole batch-norm
+                                   backward of the target layer inside the data-gradient conv that makes its
+                                   output gradient final: the sums are exchanged within the launch like the
+                                   forward statistics, then y receives dx of the TARGET's conv output
+                                   (scale*(g - mean(g) - xhat*mean(g*xhat))) instead of the gradient wrt its
+                                   activation, and one block per channel tile writes bn_dgamma / bn_dbeta.
+                                   disyolo_conv2d_bn_fused_ok tells; same residency rule                */
 };
 
 typedef struct disyolo_conv_desc {
@@ -99,6 +121,21 @@ typedef struct disyolo_conv_desc {
   const float* bn_rstd;   /* [Cout] 1/sqrt(var+eps)                                    */
   float* bn_partials;     /* f32 [disyolo_conv2d_stats_rows][Cout][2]                  */
   float bn_alpha;         /* the target layer's leaky slope                            */
+  /* DISYOLO_CONV_BN_FUSED / DISYOLO_CONV_BN_BWD_FUSED only (else ignored): */
+  float bn_decay, bn_eps; /* moving-average decay (0.997), variance epsilon            */
+  void* y_act;            /* bf16 [B,Ho,Wo,Cout]: the activation (BN_FUSED)            */
+  const float* bn_gamma;  /* [Cout]                                                    */
+  const float* bn_beta;   /* [Cout]                                                    */
+  float* bn_moving_mean;  /* [Cout] updated in place (or NULL)                         */
+  float* bn_moving_var;   /* [Cout] updated in place (or NULL)                         */
+  float* bn_out_scale;    /* [Cout] gamma*rstd              } what the backward pass   */
+  float* bn_out_shift;    /* [Cout] beta - mean*gamma*rstd  } of this layer reads      */
+  float* bn_out_mean;     /* [Cout] batch mean                                         */
+  float* bn_out_rstd;     /* [Cout] 1/sqrt(var + eps)                                  */
+  float* bn_dgamma;       /* [Cout] (BN_BWD_FUSED)                                     */
+  float* bn_dbeta;        /* [Cout] (BN_BWD_FUSED)                                     */
+  uint32_t* cluster_sync; /* disyolo_cluster_sync_words(Cout) words, zeroed ONCE by the caller
+                             (the launches leave it zero); one buffer per layer and direction  */
 } disyolo_conv_desc;
 
 /* Host-side (no device work): the contour extraction of the dataset pre-processing, cv2.findContours(img,
@@ -114,6 +151,16 @@ int disyolo_find_contours(const uint8_t* binary, int h, int w, int32_t* points_x
 size_t disyolo_conv_desc_size(void);
 /* 1 when a call with this descriptor runs a kernel that can emit DISYOLO_CONV_BN_BWD_STATS (the patch kernel) */
 int disyolo_conv2d_bn_bwd_stats_ok(const disyolo_conv_desc* d);
+/* 1 when a call with this descriptor (shape and tile as given) can run batch norm inside the launch -- the backward form
+ * when DISYOLO_CONV_BN_BWD_FUSED is set in its flags, the forward form otherwise (DISYOLO_CONV_BN_FUSED need not be set):
+ * a kernel that has the epilogue, bf16 y, Cout % 8 == 0, and a grid that is resident at once on this device (blocks <=
+ * occupancy x compute units, queried from the runtime) with statistics rows few enough to be summed by every block */
+int disyolo_conv2d_bn_fused_ok(const disyolo_conv_desc* d);
+/* words of a `cluster_sync` buffer for a layer with Cout channels (any tile); the last word is the error word */
+int disyolo_cluster_sync_words(int Cout);
+/* 0, or the code a bounded in-launch wait left in the buffer's error word (device memory is read with a blocking copy:
+ * call it at a synchronisation point, e.g. when the losses are fetched) */
+int disyolo_cluster_sync_error(const uint32_t* cluster_sync, int Cout);
 /* rows of the `stats` partial buffer a call with this descriptor writes */
 int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d);
 int disyolo_conv2d_fwd(const disyolo_conv_desc* d, void* stream);
@@ -508,6 +555,10 @@ void* disyolo_cmdlist_lane_stream(void* list, int lane);   /* lane 1..3 (side_st
  * lane i) creates them NOW on the current device -- before torch.distributed's NCCL backend (whose stream pool takes
  * the hardware queues: a lane created afterwards may share the caller's stream's queue, 2.5x the step time) */
 int disyolo_lanes_reserve(int mask);
+/* how the side lanes of the current device were chosen, one text line per lane that exists (priority, probed or not,
+ * candidates tried, whether the fallback was taken, the probe's times): bench.py puts it into its line so that a run that
+ * fell back to an unmeasured stream can be told from one that did not */
+int disyolo_lanes_report(char* buf, int size);
 
 /* ---- data-parallel gradient exchange as COMMANDS of the step (csrc/comm.hip) ----
  * The reference trains on one GPU (yolo/config.py:18; the op being distributed is train_yolo3_mask.py:55-56,

@@ -36,8 +36,9 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_table_matches_header():
     assert sorted(L.EXPORTS) == declared_functions()
     assert L.load().disyolo_version() >= 100
-    # 16 x int32/float + 8 pointers, + 6 pointers and a float (padded) of the batch-norm backward epilogue
-    assert ctypes.sizeof(L.ConvDesc) == L.load().disyolo_conv_desc_size() == 184
+    # 16 x int32/float + 8 pointers, + 6 pointers and a float of the batch-norm backward epilogue, + 2 floats (padded) and
+    # 12 pointers of the in-launch batch norm (round 6)
+    assert ctypes.sizeof(L.ConvDesc) == L.load().disyolo_conv_desc_size() == 288
 
 
 def test_argument_errors_are_reported_not_thrown():

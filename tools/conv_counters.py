@@ -79,7 +79,7 @@ def report(dirs, out):
                     continue
                 key = (name, int(r["Grid_Size"]) // max(1, int(r.get("Workgroup_Size", 1) or 1)))
                 acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
-                n[key, r["Counter_Name"]].add(r["Dispatch_Id"])
+                n[key, r["Counter_Name"]].add((d, r["Dispatch_Id"]))       # (a counter collected in both passes: both count)
     lines = []
     hdr = "%-44s %6s %9s %7s %7s %7s %7s %9s %8s %8s %7s" % (
         "kernel", "blocks", "wavecyc/l", "parked", "stalled", "st_lds", "issuing", "mfma/simd", "lds_act", "lds_cnfl", "coexec")
@@ -105,7 +105,7 @@ def report(dirs, out):
     lines.append("")
     lines.append("parked = SQ_WAIT_ANY, stalled = SQ_WAIT_INST_ANY (st_lds = its SQ_WAIT_INST_LDS part), issuing = SQ_ACTIVE_INST_ANY, each / SQ_WAVE_CYCLES;")
     lines.append("mfma/simd, lds_act, lds_cnfl, coexec = SQ_VALU_MFMA_BUSY_CYCLES, SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT, SQ_VALU_MFMA_COEXEC_CYCLES")
-    lines.append("(cycles) / (4 x SQ_WAVE_CYCLES quad-cycles) = per cycle of WAVE lifetime; x waves per SIMD = the SIMD's (MFMA) or, x waves per CU / ... see profiles text.")
+    lines.append("(cycles) / (4 x SQ_WAVE_CYCLES quad-cycles) = per cycle of ONE wave's lifetime: x waves per SIMD = the SIMD's MFMA pipe, x waves per CU = the CU's LDS array.")
     txt = "\n".join(lines)
     print(txt)
     if out:
