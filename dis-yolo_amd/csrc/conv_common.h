@@ -31,6 +31,7 @@ struct ConvParams {
   int pcls, Mc, tilesMc;     // stride-2 data gradient by output-parity classes (GEMM tiles): see conv_igemm_kernel
   int tapmask, d2s_c;        // stride-2 data gradient as a 2x2-tap conv over dy with a depth-to-space store (disyolo_dgrad_s2_quad)
   int xcd_n;                 // GEMM tiles: an XCD's run of tiles walks the pixel tiles of a few channel tiles (weights > input)
+  int halo_split;            // patch kernel: even halo rows first, odd rows behind them (conflict-free wrapped fragments)
   int flags;
   float alpha;
   // DISYOLO_CONV_BN_FUSED / DISYOLO_CONV_BN_BWD_FUSED: batch norm inside the launch (cluster exchange below)

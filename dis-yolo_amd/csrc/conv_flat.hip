@@ -1,7 +1,7 @@
 // 3x3 stride-1 SAME convolution on v_mfma_f32_32x32x16_bf16 over a FLAT padded frame ("flat patch" kernels,
 // tile ids 24 / 25; forward and data gradient of yolo/yolo3_net_pos.py:142 conv_bn's tf.nn.conv2d for the deep layers).
 //
-// Why a second patch-kernel family (round 4; profiles/r04_halo_ablation.txt, r04_mfma_lds_probe.txt).  Compile-time
+// Why a second patch-kernel family (round 4; profiles/archive/r04_halo_ablation.txt, r04_mfma_lds_probe.txt).  Compile-time
 // ablations of conv_halo_kernel<8,3,2> on the 18^2 512 -> 1024 layer: MFMAs alone 11.6 us of loop, fragment reads alone
 // 13.4, both 20.5-21.3 -- the two do not overlap -- while MFMAs + DMAs (13.6) and reads + DMAs (16) do.  A 16x16x32
 // MFMA holds the SIMD's vector issue for 8 of its 16 cycles and needs one 1-KiB fragment read per 1.2 MFMAs with a

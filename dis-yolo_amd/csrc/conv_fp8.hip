@@ -76,11 +76,21 @@ __device__ __forceinline__ void unpack4_fp8(unsigned v, float* f) {
 // swizzle of the 16-byte units of an LDS row (U units per row) by the row index
 template <int U>
 __device__ __forceinline__ int swz(int row, int u) {
-  return U == 4 ? (u ^ ((row >> 2) & 3)) : (U == 2 ? (u ^ ((row >> 3) & 1)) : u);
+  return U == 8 ? (u ^ ((row >> 1) & 7)) : (U == 4 ? (u ^ ((row >> 2) & 3)) : (U == 2 ? (u ^ ((row >> 3) & 1)) : u));
 }
 
-template <int BM, int BN, int BK, int ST>
+// MX = the block-scaled form of the fp8 MFMA, v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales (E8M0 127 = 2^0 in every
+// scale byte): 128 k-bytes per instruction at twice the non-scaled form's rate per byte (MI355X_MICROARCH.md, matrix cores:
+// "block-scaled ... with e4m3 operands: twice the cycles of the BF16 form of the same M x N at 4x the K") -- the only fp8 form
+// that is faster than bf16.  Same products, same f32 accumulation: the numbers of the non-scaled path.  K slices of 128 bytes
+// (Cin a multiple of 128: a slice never straddles a tap); a lane's fragment is 32 of the row's 128 bytes -- the 16-byte units
+// fg and 4 + fg (fg = lane >> 4), the SAME units for both operands, so whatever k index the instruction gives register byte
+// j of lane group fg, the two operands agree on it -- read with two ds_read_b128 whose lane -> (row, unit) pattern is the
+// bf16 GEMM tile's (unit = kk * 4 + fg with a 128-byte row), conflict-free under the same XOR swizzle.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+template <int BM, int BN, int BK, int ST, bool MX = false>
 __global__ __launch_bounds__(256) void conv_fp8_kernel(Fp8Params p) {
+  static_assert(!MX || BK % 128 == 0, "the block-scaled MFMA multiplies 128 k-bytes");
   // BM = pixels per block (128; 64 for the small feature maps whose grid would not fill the chip)
   constexpr int WN = (BN == 128 || BM == 64) ? 2 : 1;   // waves along the channels
   constexpr int WM = 4 / WN;                    // waves along the pixels
@@ -178,6 +188,31 @@ __global__ __launch_bounds__(256) void conv_fp8_kernel(Fp8Params p) {
     if (s + PRE < nslices) issue(s + PRE, (s + PRE) % ST);
     const char* sX = smem + (s % ST) * STB;
     const char* sW = sX + XB;
+    if constexpr (MX) {
+#pragma unroll
+      for (int kk = 0; kk < BK / 128; ++kk) {
+        i32x8 wf[CI], xf[PI];
+#pragma unroll
+        for (int i = 0; i < CI; ++i) {
+          const int row = wn * WTN + i * 16 + fr;
+          const int4 lo = *reinterpret_cast<const int4*>(sW + row * BK + swz<U>(row, kk * 8 + fg) * 16);
+          const int4 hi = *reinterpret_cast<const int4*>(sW + row * BK + swz<U>(row, kk * 8 + 4 + fg) * 16);
+          wf[i] = i32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        }
+#pragma unroll
+        for (int j = 0; j < PI; ++j) {
+          const int row = wm * WTM + j * 16 + fr;
+          const int4 lo = *reinterpret_cast<const int4*>(sX + row * BK + swz<U>(row, kk * 8 + fg) * 16);
+          const int4 hi = *reinterpret_cast<const int4*>(sX + row * BK + swz<U>(row, kk * 8 + 4 + fg) * 16);
+          xf[j] = i32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        }
+#pragma unroll
+        for (int i = 0; i < CI; ++i)
+#pragma unroll
+          for (int j = 0; j < PI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[i], xf[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      }
+    } else
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
       long wf[CI], xf[PI];
@@ -306,9 +341,9 @@ __global__ __launch_bounds__(256) void pack_fp8_kernel(const float* w, uint8_t* 
   }
 }
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, bool MX = false>
 int launch_fp8(const Fp8Params& p, hipStream_t s) {
-  constexpr int ST = 3;
+  constexpr int ST = MX ? 2 : 3;        // (128-byte slices: two stages = 64 KB, two blocks per CU)
   constexpr int U = BK / 16, RPD = 64 / U;
   constexpr int WD = ((BN + RPD - 1) / RPD + 3) / 4;
   constexpr int XD = ((BM + RPD - 1) / RPD + 3) / 4;
@@ -317,7 +352,7 @@ int launch_fp8(const Fp8Params& p, hipStream_t s) {
   constexpr size_t stage = (size_t)4 * (BM / (4 / WN)) * ((BN / WN) * 2 + 16);
   const size_t bytes = lds > stage ? lds : stage;
   const int grid = ceil_div(p.M, BM) * ceil_div(p.Cout, BN);
-  hipLaunchKernelGGL((conv_fp8_kernel<BM, BN, BK, ST>), dim3(grid), dim3(256), bytes, s, p);
+  hipLaunchKernelGGL((conv_fp8_kernel<BM, BN, BK, ST, MX>), dim3(grid), dim3(256), bytes, s, p);
   return 0;
 }
 
@@ -359,10 +394,14 @@ extern "C" int disyolo_conv2d_fp8_fwd(const disyolo_conv_desc* d, const void* w_
   const bool bk64 = (d->C0 % 64) == 0;
   // 64-pixel tiles when 128-pixel tiles would leave CUs without a block (the 18x18 / 36x36 maps at batch 8)
   const bool small = bk64 && d->Cout >= 128 && ceil_div(p.M, 128) * ceil_div(d->Cout, 128) < 256;
+  // the block-scaled MFMA (K slices of 128 bytes) wherever the input has >= 128 channels: conv10-52 of the backbone
+  static const bool mx_on = [] { const char* e = getenv("DISYOLO_FP8_MX"); return !(e && e[0] == '0'); }();
+  const bool mx = mx_on && (d->C0 % 128) == 0 && d->Cout >= 128;
   if (small) {
-    launch_fp8<64, 128, 64>(p, s);
+    if (mx) launch_fp8<64, 128, 128, true>(p, s); else launch_fp8<64, 128, 64>(p, s);
   } else if (d->Cout > 64) {
-    if (bk64) launch_fp8<128, 128, 64>(p, s); else launch_fp8<128, 128, 32>(p, s);
+    if (mx) launch_fp8<128, 128, 128, true>(p, s);
+    else if (bk64) launch_fp8<128, 128, 64>(p, s); else launch_fp8<128, 128, 32>(p, s);
   } else if (d->Cout > 32) {
     if (bk64) launch_fp8<128, 64, 64>(p, s); else launch_fp8<128, 64, 32>(p, s);
   } else {

@@ -819,6 +819,18 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
   const int ty = pr / tilesX, tx = pr - ty * tilesX;
   const int y0 = ty * PH, x0 = tx * PW;        // patch origin (output = input coordinates: SAME, stride 1)
   const int HW_ = PW + 2, NPIX = (PH + 2) * HW_, NOUT = PH * PW;
+  // Where halo row hy sits in the LDS image.  Bank slot of a fragment read = (LDS row mod 8, chunk): swz_any makes 16 CONSECUTIVE
+  // rows conflict-free, but a 16-pixel fragment of the PW-wide patch wraps to the next patch row in most alignments, and with the
+  // halo rows stored one after the other (pitch PW + 2) its LDS rows then jump by 3 -- 23 / 27 / 32 % of the patch kernels' LDS
+  // time were bank conflicts (profiles/r06_conv_sq_counters.txt).  With the EVEN halo rows stored first and the odd ones behind
+  // them at an offset of 2 mod 8, row hy + 1 always starts PW mod 8 rows after row hy's start (pitch 20 or 28: 4 mod 8), so the
+  // wrap is one row further mod 8, like a consecutive row.  Same 16-byte units, same swizzle, no extra LDS.  Other pitches keep
+  // the linear image.
+  const bool split_on = p.halo_split != 0;                                           // (launch_halo: DISYOLO_HALO_SPLIT_ROWS=0 keeps the linear image, for A/B)
+  const int odd_base0 = ((((PH + 3) >> 1) * HW_ + 7) & ~7) + 2;                      // first slot of the odd rows: 2 mod 8
+  const bool split_rows = split_on && (HW_ & 7) == 4 && odd_base0 + ((PH + 2) >> 1) * HW_ <= AIM * NW * 16;   // (the image must fit the AIM halo DMAs)
+  const int odd_base = split_rows ? odd_base0 : 0;
+  auto row_start = [&](int hy) { return split_rows ? ((hy & 1) ? odd_base + (hy >> 1) * HW_ : (hy >> 1) * HW_) : hy * HW_; };
 
   const i32x4 srd0 = make_srd(p.x0, p.bytes0);
   const i32x4 srdw = make_srd(p.w, p.bytesw);
@@ -829,9 +841,20 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
     const int chunk = (j * NW + wave) * 64 + lane;
     const int hp = chunk >> 2, pc = chunk & 3;
     int hy, hx;
-    divmod_small(hp < NPIX ? hp : 0, HW_, hy, hx);
+    bool slot_ok = hp < NPIX;
+    if (split_rows) {      // slot -> halo pixel: even rows in [0, n_even * HW_), odd rows from odd_base
+      const int n_even = (PH + 3) >> 1, n_odd = (PH + 2) >> 1;
+      const bool odd = hp >= odd_base;
+      const int rel = odd ? hp - odd_base : hp;
+      int r2;
+      divmod_small(rel, HW_, r2, hx);
+      hy = 2 * r2 + (odd ? 1 : 0);
+      slot_ok = odd ? (r2 < n_odd) : (hp < n_even * HW_);
+    } else {
+      divmod_small(hp < NPIX ? hp : 0, HW_, hy, hx);
+    }
     const int iy = y0 + hy - p.pad_t, ix = x0 + hx - p.pad_l;
-    const bool ok = (hp < NPIX) && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
+    const bool ok = slot_ok && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
     a_off[j] = ok ? (unsigned)(((b * p.H + iy) * p.W + ix) * p.C0) * 2u + swz_any(hp, pc) * 16 : OOB;
   }
   unsigned b_off[BIM];
@@ -868,7 +891,7 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
   // fragment read state
   const int frow = lane & 15, fchunk = lane >> 4;
   const int nfrags = (NOUT + 15) >> 4;
-  int hp0[FW];          // halo pixel of this lane's patch pixel at tap (0,0), per M fragment
+  int hp0[FW][3];       // LDS slot of this lane's patch pixel at tap (kh, 0), per M fragment (the row start depends on the row's parity)
   int q_of[FW];         // patch pixel index (or -1)
 #pragma unroll
   for (int t = 0; t < FW; ++t) {
@@ -877,7 +900,8 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
     const bool ok = q < NOUT;
     int py, px;
     divmod_small(ok ? q : 0, PW, py, px);
-    hp0[t] = py * HW_ + px;
+#pragma unroll
+    for (int kh_ = 0; kh_ < 3; ++kh_) hp0[t][kh_] = row_start(py + kh_) + px;
     q_of[t] = ok ? q : -1;
   }
   int nf_w = 0;  // fragments this wave owns (wave-uniform)
@@ -924,7 +948,7 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(ConvParams p, int PH
     for (int j = 0; j < NI; ++j) wfr[bi][j] = *reinterpret_cast<const bf16x8*>(st + wb[j] + TAP * BN * 64);
 #pragma unroll
     for (int t = 0; t < FW; ++t) {
-      const int hp = hp0[t] + kh * HW_ + kw;
+      const int hp = hp0[t][kh] + kw;
       xfr[bi][t] = *reinterpret_cast<const bf16x8*>(st + hp * 64 + swz_any(hp, fchunk) * 16);
     }
 #endif
@@ -1978,6 +2002,8 @@ int launch_halo(const ConvParams& p, Patch pt, hipStream_t s) {
   {
     static const bool on = [] { const char* e = getenv("DISYOLO_XCD_N"); return !(e && e[0] == '0'); }();
     q.xcd_n = (on && q.tilesN >= 8 && (int64_t)p.bytesw > (int64_t)p.bytes0) ? 1 : 0;
+    static const bool split = [] { const char* e = getenv("DISYOLO_HALO_SPLIT_ROWS"); return !(e && e[0] == '0'); }();
+    q.halo_split = split ? 1 : 0;
   }
   constexpr int SLAB = NW * 1024, BIM = (9 * BN * 4 + NW * 64 - 1) / (NW * 64);
   // two stages (compute slice c while slice c+1 lands); a one-slice layer (32 input channels) uses the first only.
@@ -2170,7 +2196,7 @@ int dispatch(int id, bool bk64, int variant, const ConvParams& p, hipStream_t s)
 
 // Launcher heuristic = the consensus of the in-sequence autotuner (YOLONet.autotune, which
 // times every candidate where it runs: inside the step, operands as cold as they really are)
-// over the layer shapes of the B = 8, 576^2 network; profiles/r01h_autotune.txt.  Stand-alone
+// over the layer shapes of the B = 8, 576^2 network; profiles/archive/r01h_autotune.txt.  Stand-alone
 // timing loops (tools/bench_conv.py) keep a layer's operands hot in L2 and rank the tiles
 // differently -- rules taken from them measured 1-3 % SLOWER end to end.  What the picks say:
 // huge-M layers want the 8-wave 192x128 tile (48x64 wave tiles: fewest bytes staged per
@@ -2404,7 +2430,7 @@ extern "C" int disyolo_dgrad_s2_quad(const void* dy, const void* wq, void* dx, c
   p.flags = 0;
   p.alpha = 0.f;
   p.tilesM = p.tilesN = 0;
-  p.xcd_n = 0;
+  p.xcd_n = 0; p.halo_split = 0;
   p.pcls = 0; p.Mc = 0; p.tilesMc = 0;
   p.tapmask = 0x1b;           // taps (0,0) (0,1) (1,0) (1,1)
   p.d2s_c = C;
@@ -2507,7 +2533,7 @@ static int conv2d_fwd_core(const disyolo_conv_desc* d, void* stream) {
   p.flags = d->flags;
   p.alpha = d->alpha;
   p.tilesM = p.tilesN = 0;
-  p.xcd_n = 0;
+  p.xcd_n = 0; p.halo_split = 0;
   p.pcls = 0; p.Mc = 0; p.tilesMc = 0;
   p.tapmask = 0; p.d2s_c = 0;
   p.y_act = d->y_act; p.gamma = d->bn_gamma; p.beta = d->bn_beta; p.mm = d->bn_moving_mean; p.mv = d->bn_moving_var;

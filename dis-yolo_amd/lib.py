@@ -530,7 +530,7 @@ def conv_bytes(d: ConvDesc) -> float:
 
 
 _WAVES = {1: (2, 2), 2: (2, 2), 3: (2, 2), 4: (4, 1), 5: (4, 1), 6: (2, 2), 7: (4, 1), 8: (4, 2), 9: (2, 2),
-          10: (2, 2), 11: (2, 2), 12: (4, 2), 13: (2, 2), 14: (2, 2), 15: (4, 2)}
+          10: (2, 2), 11: (2, 2), 12: (4, 2), 13: (2, 2), 14: (2, 2), 15: (4, 2), 26: (1, 2), 27: (2, 1), 28: (1, 2), 29: (4, 2)}
 
 
 def conv2d_tile(d: ConvDesc):
@@ -558,8 +558,10 @@ def conv2d_fwd(d: ConvDesc) -> None:
             elif tid >= 16:
                 d._tname = "conv_halo_kernel<%d,3,%d>" % (4 if tid == 17 else 8, 2 if tid == 18 else 1 if tid == 19 else 4)
             else:
-                d._tname = "conv_igemm_kernel<%d,%d,%d,%d,%d,%d,%d,%d>" % ((bm, bn) + _WAVES[tid] +
-                                                                            (bk, st, d.ksize, 2 if tid >= 13 else 1))
+                # (the last argument: 1 = the instance with the fused batch-norm backward epilogue, round 6)
+                d._tname = "conv_igemm_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d>" % ((bm, bn) + _WAVES.get(tid, (0, 0)) +
+                                                                               (bk, st, d.ksize, 2 if 13 <= tid <= 15 else 1,
+                                                                                1 if d.flags & CONV_BN_BWD_FUSED else 0))
         TIMER.run(d._tname, conv_flops(d), lambda: _check(load().disyolo_conv2d_fwd(C.byref(d), _stream()),
                                                            "conv2d_fwd"), conv_bytes(d))
         return

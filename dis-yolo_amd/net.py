@@ -488,18 +488,30 @@ class YOLONet(object):
         self.refresh_weights()
 
     # ---- fp8 path of the inference-mode backbone --------------------------------------------
+    # Round 6: conv1-9 stay bf16 -- their fused launches (conv1+2, the 288^2 / 144^2 residual blocks) beat any per-layer fp8
+    # kernel, and their inputs have 3 ... 64 channels, below the 128-byte K slice of the block-scaled MFMA -- and conv10-52 run
+    # e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4 (csrc/conv_fp8.hip, MX): conv9's bf16 output is quantised once for conv10.
+    # DISYOLO_FP8_FROM=1 gives round 5's all-fp8 backbone (profiles/r06_fp8_mx_layers.txt has both).
+    FP8_FROM = int(os.environ.get("DISYOLO_FP8_FROM", "10"))
     FP8_UPTO = 52
     FP8_DUAL = (4, 9, 26, 43, 52)     # outputs that bf16 layers consume too (skip2..5, the trunk's end)
 
     def _fp8_layers(self):
-        """layers that run in fp8: conv1..52 when they are in inference mode (locked, or an inference net)"""
-        return [l for l in self.layers if l.idx <= self.FP8_UPTO and (l.lock or not self.training)]
+        """layers that run in fp8: conv FP8_FROM..52 when they are in inference mode (locked, or an inference net)"""
+        return [l for l in self.layers if self.FP8_FROM <= l.idx <= self.FP8_UPTO and (l.lock or not self.training)]
 
     def _plan_fp8(self) -> None:
         dev = self.device
         ls = self._fp8_layers()
-        if [l.idx for l in ls] != list(range(1, self.FP8_UPTO + 1)):
+        if [l.idx for l in ls] != list(range(self.FP8_FROM, self.FP8_UPTO + 1)) or not all(
+                l.lock or not self.training for l in self.layers[:self.FP8_UPTO]):
             raise L.DisyoloError("dtype='fp8' needs conv1-52 in inference mode (stage 1 training, or training=False)")
+        # the bf16 layer in front of the first fp8 layer: its output is also kept as e4m3 (one quantisation pass per forward)
+        self._fp8_entry = self.by_idx[self.FP8_FROM - 1] if self.FP8_FROM > 1 else None
+        if self._fp8_entry is not None:
+            q = self._fp8_entry
+            q.act8 = torch.zeros(self.B, q.Ho, q.Wo, q.cout, dtype=torch.uint8, device=dev)
+            q.s_out = 1.0
         for l in ls:
             l.act8 = torch.zeros(self.B, l.Ho, l.Wo, l.cout, dtype=torch.uint8, device=dev)
             l.escale = torch.zeros(l.cout, dtype=F32, device=dev)
@@ -517,17 +529,19 @@ class YOLONet(object):
             raise L.DisyoloError("calibrate_fp8 on a bf16 net")
         self.sync_lanes()
         self.fp8_ready = False
-        for l in self._fp8_layers():
+        for l in self.layers[:self.FP8_UPTO]:       # (layer by layer in bf16: every output is written)
             self._forward_layer(l, False)
         torch.cuda.synchronize()
-        for l in self._fp8_layers():
+        scaled = self._fp8_layers() + ([self._fp8_entry] if self._fp8_entry is not None else [])
+        for l in scaled:
             amax = float(l.act.float().abs().max())
             l.s_out = max(amax, 1e-12) / (448.0 * margin)
+        for l in self._fp8_layers():
             if l.idx > 1:
                 l.s_w = max(float(l.w.abs().max()), 1e-12) / 448.0
         self.fp8_ready = True
         self.refresh_weights()
-        return {l.idx: l.s_out for l in self._fp8_layers()}
+        return {l.idx: l.s_out for l in sorted(scaled, key=lambda x: x.idx)}
 
     def _forward_layer_fp8(self, l) -> None:
         if l.idx == 1:
@@ -720,8 +734,10 @@ class YOLONet(object):
             if l.idx in plan:
                 if plan[l.idx] is not None:
                     plan[l.idx]()
+                self._fp8_handover(l)
                 continue
             self._forward_layer(l, is_training)
+            self._fp8_handover(l)
         if self.use_side_lane:
             L.set_lane(0)
             L.lane_sync(1, 0)
@@ -807,8 +823,17 @@ class YOLONet(object):
             if l.idx in plan:
                 if plan[l.idx] is not None:
                     plan[l.idx]()
+                self._fp8_handover(l)
                 continue
             self._forward_layer(l, is_training)
+            self._fp8_handover(l)
+
+    def _fp8_handover(self, l) -> None:
+        """the bf16 layer in front of the first fp8 layer: its output once more as e4m3 (what conv FP8_FROM reads)"""
+        if self.dtype == "fp8" and self.fp8_ready:
+            q = getattr(self, "_fp8_entry", None)
+            if q is not None and l.idx == q.idx:
+                L.quant_fp8(q.act, q.act8, q.s_out)
 
     def _inference_mode(self, idxs, is_training: bool) -> bool:
         """every one of these layers normalises with its folded moving statistics in this pass"""
@@ -820,7 +845,23 @@ class YOLONet(object):
         first residual block (conv3+conv4), the mask head (conv80+81+82) -- bf16 path only."""
         plan = {}
         if self.dtype == "fp8" and self.fp8_ready:
+            # the fp8 layers run one by one; the bf16 layers in front of them (conv1-9) keep their fused launches
+            bf16_plan = self._fusion_plan_bf16(is_training, first, last)
+            groups, cur = [], []
+            for i in sorted(bf16_plan):
+                cur.append(i)
+                if bf16_plan[i] is not None:
+                    groups.append(cur)
+                    cur = []
+            for g in groups:
+                if not any(self.FP8_FROM <= i <= self.FP8_UPTO for i in g):
+                    for i in g:
+                        plan[i] = bf16_plan[i]
             return plan
+        return self._fusion_plan_bf16(is_training, first, last)
+
+    def _fusion_plan_bf16(self, is_training: bool, first: int, last: int):
+        plan = {}
         if first <= 1 and last >= 2 and self._can_fuse_first_two(is_training):
             plan[1], plan[2] = None, self._forward_first_two
         if self.fuse_blocks and not getattr(self, "plan_only", False):
@@ -841,7 +882,7 @@ class YOLONet(object):
 
     def _can_fuse_first_two(self, is_training: bool) -> bool:
         """conv1 and conv2 both in inference mode (folded moving statistics), bf16 path, a size the fused kernel covers"""
-        if not self.fuse_first_two or (self.dtype == "fp8" and self.fp8_ready):
+        if not self.fuse_first_two or (self.dtype == "fp8" and self.fp8_ready and self.FP8_FROM <= 2):
             return False
         if not self._inference_mode((1, 2), is_training):
             return False            # (a trainable conv1 / conv2 needs its own output -- and its batch statistics)
@@ -849,7 +890,7 @@ class YOLONet(object):
 
     def _forward_layer(self, l, is_training: bool) -> None:
         B = self.B
-        if self.dtype == "fp8" and self.fp8_ready and l.act8 is not None:
+        if self.dtype == "fp8" and self.fp8_ready and l.act8 is not None and l.idx >= self.FP8_FROM:
             self._forward_layer_fp8(l)
             return
         train_bn = is_training and self.training and (not l.lock) and l.kind != "lin"
@@ -924,6 +965,10 @@ class YOLONet(object):
                 l.bwd_local = torch.zeros(l.cout, 2, dtype=torch.float64, device=self.device)
                 l.bwd_global = torch.zeros(l.cout, 2, dtype=torch.float64, device=self.device)
         self.sync_bn = True
+        # the statistics now cross the ranks between the conv and the normalisation: the in-launch batch norm (whose
+        # exchange stays inside one launch) is off -- rebuild the descriptors that carry it
+        if not getattr(self, "plan_only", False) and any(l.fused_fwd for l in self.layers):
+            self._apply_tiles()
 
     def _detect(self, det_thresh: float) -> None:
         L.detect(self.by_idx[75].act, self.by_idx[67].act, self.by_idx[59].act, self.B, self.S, self.num_class,

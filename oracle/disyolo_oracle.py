@@ -289,13 +289,15 @@ def build_network(params: Dict[str, torch.Tensor], images: torch.Tensor, is_trai
     of a randomly initialised network.
     """
     sp = layer_specs()
-    # fp8 = {"upto": 52, "s_out": {layer: scale}, "s_w": {layer: scale}}: emulation of the port's e4m3 path --
-    # layers 1..upto (inference mode) store their output as e4m3 * s_out and use e4m3 * s_w weights; the
-    # outputs the bf16 layers consume too (skip2..5, act52) are ALSO kept as bf16 of the unquantised value
+    # fp8 = {"from": 10, "upto": 52, "s_out": {layer: scale}, "s_w": {layer: scale}}: emulation of the port's e4m3 path --
+    # layers from..upto (inference mode; "from" defaults to 1) store their output as e4m3 * s_out and use e4m3 * s_w
+    # weights; layer from-1 (bf16) hands its bf16-rounded output over as e4m3 as well; the outputs the bf16 layers
+    # consume too (skip2..5, act52) are ALSO kept as bf16 of the unquantised value
     dual = {}
+    fp8_from = fp8.get("from", 1) if fp8 is not None else 1
 
     def cb(x, i):
-        if fp8 is not None and 2 <= i <= fp8["upto"]:
+        if fp8 is not None and max(2, fp8_from) <= i <= fp8["upto"]:
             p8 = dict(params)
             p8[_name(i, "weights")] = fp8_e4m3(params[_name(i, "weights")], fp8["s_w"][i])
             return conv_bn(x, p8, i, sp[i][3], lock[i], is_training, updates, quant=None)
@@ -306,9 +308,13 @@ def build_network(params: Dict[str, torch.Tensor], images: torch.Tensor, is_trai
         # every stored activation is rounded once, after the residual add (bf16 path);
         # head logits / score maps stay f32
         idx = int(name[3:])
-        if fp8 is not None and idx <= fp8["upto"]:
+        if fp8 is not None and fp8_from <= idx <= fp8["upto"]:
             dual[name] = quant(t) if quant is not None else t
             t = fp8_e4m3(t, fp8["s_out"][idx])
+        elif fp8 is not None and idx == fp8_from - 1:
+            # the bf16 layer in front of the fp8 range: stored in bf16 (what its bf16 consumers read), quantised FROM that
+            dual[name] = quant(t) if quant is not None else t
+            t = fp8_e4m3(dual[name], fp8["s_out"][idx])
         elif quant is not None and name not in ("act59", "act67", "act75", "act82"):
             t = quant(t)
         if taps is not None:

@@ -241,6 +241,7 @@ def test_training_step_with_and_without_inkernel_batch_norm_agree(dev):
         net.bn_inkernel_bwd = on
         net._apply_tiles()
         batch = synthetic_batch(2, 288, seed=5)
+        w0 = net.arena.clone()
         losses = [float(net.train_step(batch, det_thresh=0.3).cpu()) for _ in range(3)]
         torch.cuda.synchronize()
         nf = sum(1 for l in net.layers if l.fused_fwd)
@@ -253,9 +254,15 @@ def test_training_step_with_and_without_inkernel_batch_norm_agree(dev):
                         assert L.cluster_sync_error(buf, l.cout) == 0
         else:
             assert nf == 0 and nb == 0
-        res.append((losses, net.arena.clone(), {n: p.clone() for n, p in net.params.items() if "moving" in n}))
-    (la, wa, ma), (lb, wb, mb) = res
+        res.append((losses, net.arena.clone(), {n: p.clone() for n, p in net.params.items() if "moving" in n}, w0))
+    (la, wa, ma, w0a), (lb, wb, mb, w0b) = res
+    assert torch.equal(w0a, w0b)
     np.testing.assert_allclose(la, lb, rtol=2e-3)
-    assert float((wa - wb).double().norm() / wb.double().norm()) < 1e-3
+    # three Adam steps from zero moments move every variable by ~lr per step in the direction of its gradient's SIGN: a gradient
+    # at rounding-noise level may flip -- the variables agree to a fraction of the 3-step update, whose directions coincide
+    ua, ub = (wa - w0a).double(), (wb - w0b).double()
+    assert float((wa - wb).double().norm() / ub.norm()) < 0.25
+    assert float((ua @ ub) / (ua.norm() * ub.norm())) > 0.97
+    assert float((wa - wb).double().norm() / wb.double().norm()) < 5e-3
     for n in ma:
         torch.testing.assert_close(ma[n], mb[n], rtol=1e-3, atol=1e-4)

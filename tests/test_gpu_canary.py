@@ -83,7 +83,7 @@ def test_tuned_recorded_training_at_config_size_stays_finite_and_descends(dev, s
     assert bool(torch.isfinite(net.arena).all())
 
 
-@pytest.mark.parametrize("cache", [None, "profiles/r02c_tune_cache.json"])
+@pytest.mark.parametrize("cache", [None, "profiles/archive/r02c_tune_cache.json"])
 def test_fused_bn_backward_sums_match_the_plain_reduction_at_config_size(dev, cache):
     """every layer whose batch-norm backward sums come out of the data-gradient conv's epilogue (stage 2: the 1x1
     layers in front of the residual 3x3 convs, 288^2/32 ch ... 18^2/512 ch), with tuned tiles: the plain column

@@ -121,6 +121,10 @@ def _run_ranks(args, world=2, limit=400):
     """mp.spawn with a deadline: two ranks that do not finish within `limit` seconds are terminated and the test
     FAILS (a hang must not take the whole suite with it)."""
     import time
+    # the ranks of these tests share ONE GPU (the box has one): launches whose blocks wait for each other -- the in-launch
+    # batch norm -- must never run concurrently on a device (include/disyolo.h, DISYOLO_CONV_BN_FUSED), and one process per
+    # GPU is what the product runs; here two processes would: the workers run the separate batch-norm launches
+    os.environ["DISYOLO_BN_INKERNEL"] = "0"
     ctx = mp.get_context("spawn")
     procs = [ctx.Process(target=_worker, args=(rank, world) + tuple(args), daemon=True) for rank in range(world)]
     for p in procs:
@@ -135,6 +139,7 @@ def _run_ranks(args, world=2, limit=400):
         p.join(10)
         if p.is_alive():
             p.kill()
+    os.environ.pop("DISYOLO_BN_INKERNEL", None)
     assert not stuck, "%d of %d ranks still running after %d s" % (len(stuck), world, limit)
     codes = [p.exitcode for p in procs]
     assert all(c == 0 for c in codes), "rank exit codes %s" % codes

@@ -124,18 +124,20 @@ def test_fp8_inference_forward_matches_the_e4m3_emulating_oracle(dev):
     _heads(ref, 3)
     net._set_inputs(b["images"], b["clip_window"])
     s_out = net.calibrate_fp8()
-    assert len(s_out) == 52 and all(v > 0 for v in s_out.values())
+    # conv FP8_FROM .. 52 in e4m3 (10: conv1-9 keep their bf16 fused launches, round 6) + the bf16 layer that hands over to them
+    first = net.FP8_FROM
+    assert sorted(s_out) == list(range(max(first - 1, 1), 53)) and all(v > 0 for v in s_out.values())
     preds, det, mask_pos = net.forward(b["images"], b["clip_window"], [0.1], is_training=False)
     torch.cuda.synchronize()
     p = {k: v.detach().cpu().float() for k, v in net.params.items()}
-    fp8 = {"upto": 52, "s_out": s_out, "s_w": {l.idx: l.s_w for l in net.layers if l.idx <= 52 and l.idx > 1}}
+    fp8 = {"from": first, "upto": 52, "s_out": s_out, "s_w": {l.idx: l.s_w for l in net.layers if first <= l.idx <= 52 and l.idx > 1}}
     taps = {}
     yq, mq = O.build_network(p, b["images"], False, O.default_lock(1), quant=O.bf16_ste, fp8=fp8, taps=taps)
     # per layer of the free-running fp8 chain: dequantised device activations vs the emulation.  One e4m3 code
     # is 6-12 % of a value; an f32 summation-order difference flips a rounding now and then and the flips
     # propagate, so the distance grows slowly with depth (measured: 0.5 % at conv2, ~4 % at conv10-52)
     worst = 0.0
-    for l in net.layers[:52]:
+    for l in net.layers[max(first - 2, 0):52]:
         got = torch.zeros(l.act8.numel(), device=dev)
         L.dequant_fp8(l.act8, got, l.s_out)
         r = rel(got.view(l.act8.shape), taps["act%d" % l.idx])
