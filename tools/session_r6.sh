@@ -1,0 +1,113 @@
+#!/bin/bash
+# Round 6: the gpurun calls of the round, one shell function per call (run on the GPU box from the repository root:
+#   gpurun -- "bash tools/session_r6.sh callN").  Outputs under gpurun_out/; what was kept is in profiles/r06_*.
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R
+
+call1() {
+  # round 6, call 1: baseline bench line + SQ counters of the 3x3 conv kernels at the round-5 tree
+  cd /tmp; export TMPDIR=/tmp
+  rocprofv3 -L > $O/r06_counters_avail.txt 2>&1
+  python3 $R/tools/conv_counters.py run > $O/r06a_conv_standalone.txt 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d /tmp/cc1 -- python3 $R/tools/conv_counters.py run > $O/r06a_cc1.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_MFMA SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d /tmp/cc2 -- python3 $R/tools/conv_counters.py run > $O/r06a_cc2.log 2>&1
+  python3 $R/tools/conv_counters.py report /tmp/cc1 $O/r06a_conv_sq_counters.txt /tmp/cc2
+  python bench.py --no-cpu-baseline > $O/r06a_bench_stage1.json 2> $O/r06a_bench_err.txt
+  tail -c 1500 $O/r06a_bench_stage1.json
+}
+
+call2() {
+  # round 6, call 2: forward batch norm inside the conv launches -- parity, then the step with it on / off
+  timeout 900 python -m pytest tests/test_gpu_bn_inkernel.py -x -q > $O/r06b_test_inkernel.txt 2>&1; echo "inkernel rc=$?" 
+  tail -15 $O/r06b_test_inkernel.txt
+  timeout 1200 python -m pytest tests/test_gpu_net.py -x -q > $O/r06b_test_net.txt 2>&1; echo "net rc=$?"
+  tail -5 $O/r06b_test_net.txt
+  for v in 1 0 1 0; do
+    DISYOLO_BN_INKERNEL=$v timeout 600 python bench.py --no-cpu-baseline --no-secondary --no-box 2> $O/r06b_bench_err_$v.txt | python3 -c "
+  import sys, json
+  d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+  print('INKERNEL=$v', d['value'], d['ms_per_step'], d['ms_per_step_min_max'], d['config']['loss_last'])
+  "
+  done
+}
+
+call5() {
+  timeout 900 python -m pytest tests/test_gpu_bn_inkernel.py -x -q > $O/r06c_test_inkernel.txt 2>&1; echo "inkernel rc=$?"
+  tail -25 $O/r06c_test_inkernel.txt
+  timeout 1200 python -m pytest tests/test_gpu_net.py -x -q > $O/r06c_test_net.txt 2>&1; echo "net rc=$?"
+  tail -5 $O/r06c_test_net.txt
+  for v in "1 1" "1 0" "0 0" "1 1" "0 0"; do
+    set -- $v
+    DISYOLO_BN_INKERNEL=$1 DISYOLO_BN_INKERNEL_BWD=$2 timeout 600 python bench.py --no-cpu-baseline --no-secondary --no-box 2> $O/r06c_bench_err_$1$2.txt | python3 -c "
+  import sys, json
+  d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+  print('INKERNEL=$1 BWD=$2', d['value'], d['ms_per_step'], d['ms_per_step_min_max'], d['config']['loss_last'])
+  "
+  done
+}
+
+call9() {
+  run() { echo "=== $*"; env "$@" timeout 120 python tools/bn_inkernel_debug.py 8 $MODE 2>&1 | grep -v amdgpu.ids | head -12; }
+  MODE=joined_nosync run A=1
+  MODE=overlap run DISYOLO_WG3_BLOCKS=64 DISYOLO_WG_BLOCKS=64
+  MODE=overlap run DISYOLO_LANE1_LOW=0
+  MODE=overlap run DISYOLO_BN_INKERNEL_BWD_GEMM=0
+  MODE=overlap run DISYOLO_OPT_OVERLAP=0
+}
+
+call10() {
+  timeout 600 python -m pytest tests/test_gpu_bn_inkernel.py -x -q > $O/r06d_test_inkernel.txt 2>&1; echo "inkernel rc=$?"
+  tail -12 $O/r06d_test_inkernel.txt
+  for m in overlap joined_nosync; do echo "== $m"; timeout 120 python tools/bn_inkernel_debug.py 8 $m 2>&1 | grep -v amdgpu.ids | head -8; done
+  for v in "1 1" "1 0" "0 0" "1 1" "0 0"; do
+    set -- $v
+    DISYOLO_BN_INKERNEL=$1 DISYOLO_BN_INKERNEL_BWD=$2 timeout 300 python bench.py --no-cpu-baseline --no-secondary --no-box 2> $O/r06d_bench_err_$1$2.txt | python3 -c "
+  import sys, json
+  d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+  print('INKERNEL=$1 BWD=$2', d['value'], d['ms_per_step'], d['ms_per_step_min_max'], d['config']['loss_last'])
+  "
+  done
+}
+
+call12() {
+  b() { env "$@" timeout 300 python bench.py --no-cpu-baseline --no-secondary --no-box 2>/dev/null | python3 -c "
+  import sys, json
+  d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+  print('$*', d['value'], d['ms_per_step'], d['ms_per_step_min_max'], d['config']['loss_last'])
+  "; }
+  for r in 1 2; do
+  b DISYOLO_BN_INKERNEL=0
+  b DISYOLO_BN_INKERNEL=1 DISYOLO_BN_INKERNEL_BWD=0
+  b DISYOLO_BN_INKERNEL=1 DISYOLO_BN_INKERNEL_BWD=0 DISYOLO_BN_INKERNEL_FWD_GEMM=0
+  b DISYOLO_BN_INKERNEL=1 DISYOLO_BN_INKERNEL_BWD=1 DISYOLO_BN_INKERNEL_BWD_GEMM=0
+  b DISYOLO_BN_INKERNEL=1 DISYOLO_BN_INKERNEL_BWD=1 DISYOLO_BN_INKERNEL_BWD_GEMM=0 DISYOLO_BN_INKERNEL_FWD_GEMM=0
+  b DISYOLO_BN_INKERNEL=1 DISYOLO_BN_INKERNEL_BWD=1
+  done
+}
+
+call15() {
+  timeout 900 python -m pytest tests/test_gpu_trajectory.py -x -q -s > $O/r06f_traj.txt 2>&1; echo "traj rc=$?"; tail -3 $O/r06f_traj.txt
+  timeout 900 python -m pytest tests/test_gpu_fp8.py tests/test_gpu_832.py -x -q > $O/r06f_fp8_tests.txt 2>&1; echo "fp8 tests rc=$?"; tail -3 $O/r06f_fp8_tests.txt
+  timeout 900 python -m pytest tests/test_gpu_dp2.py -x -q > $O/r06f_dp2.txt 2>&1; echo "dp2 rc=$?"; tail -3 $O/r06f_dp2.txt
+  for mx in 1 0; do
+    DISYOLO_FP8_MX=$mx timeout 600 python tools/bench_fp8_layers.py 4 832 > $O/r06f_fp8_layers_832_B4_mx$mx.txt 2>&1; tail -3 $O/r06f_fp8_layers_832_B4_mx$mx.txt
+    DISYOLO_FP8_MX=$mx timeout 600 python tools/bench_fp8_layers.py 32 576 > $O/r06f_fp8_layers_576_B32_mx$mx.txt 2>&1; tail -3 $O/r06f_fp8_layers_576_B32_mx$mx.txt
+  done
+}
+
+call16() {
+  timeout 1200 python -m pytest tests/test_gpu_fp8.py tests/test_gpu_832.py tests/test_gpu_conv.py tests/test_gpu_fullsize.py -x -q > $O/r06g_tests.txt 2>&1; echo "tests rc=$?"; tail -4 $O/r06g_tests.txt
+  b() { env "$@" 2>/dev/null | python3 -c "
+  import sys, json
+  d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+  print(d['config']['workload'], d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'))
+  "; }
+  C="--steps 10 --warmup 3 --repeats 5 --no-secondary --no-cpu-baseline --no-kernel-events --no-box"
+  for r in 1 2; do
+  echo "== 832 B4 train"; b timeout 300 python bench.py --size 832 --batch 4 $C --dtype bf16; b timeout 300 python bench.py --size 832 --batch 4 $C --dtype fp8; b DISYOLO_FP8_FROM=1 timeout 300 python bench.py --size 832 --batch 4 $C --dtype fp8
+  echo "== infer B32"; b timeout 300 python bench.py --task infer --batch 32 $C --dtype bf16; b timeout 300 python bench.py --task infer --batch 32 $C --dtype fp8
+  echo "== halo split rows 1/0"; b DISYOLO_HALO_SPLIT_ROWS=1 timeout 300 python bench.py --no-secondary --no-cpu-baseline --no-box; b DISYOLO_HALO_SPLIT_ROWS=0 timeout 300 python bench.py --no-secondary --no-cpu-baseline --no-box
+  done
+  for v in 1 0; do DISYOLO_HALO_SPLIT_ROWS=$v CC_ONLY=halo timeout 200 python tools/conv_counters.py run 2>&1 | grep CASE; done
+}
+
+"$@"
