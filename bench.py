@@ -44,7 +44,10 @@ MFMA_PEAK_TFLOPS = 2500.0      # bf16 dense, MI355X_MICROARCH.md "Peak BF16/FP16
 
 
 HBM_PEAK_TBS = 8.0             # spec; ~6.3 TB/s measured copy
-PMC_TRAFFIC_FILE = "r05_pmc_traffic.json" if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_pmc_traffic.json")) else "r04_pmc_traffic.json"
+# HBM bytes per launch per kernel instance from the committed PMC passes of this command (tools/profile_round.sh); the newest
+# round's file whose kernel names match this library's instances (round 6 added a template argument to conv_igemm_kernel)
+PMC_TRAFFIC_FILE = next((f for f in ("r06_pmc_traffic.json", "r05_pmc_traffic.json")
+                         if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f))), "r05_pmc_traffic.json")
 
 
 def box_fingerprint(dev, local_rank: int = 0):
@@ -340,8 +343,8 @@ def secondary_measurements(args, dev):
                                                  "conv_tiles": d["config"].get("conv_tiles"), "process": "child"}
         except Exception as e:
             out["train_stage1_backbone_pair"] = {"error": repr(e)[:200]}
-    # BASELINE.json configs[4] at its per-GPU size: 832x832, 4 images per GPU, stage 1, the locked backbone in OCP e4m3
-    # (and the same step in bf16 beside it: the non-scaled fp8 MFMA runs at the bf16 rate, fp8 can only win on bytes)
+    # BASELINE.json configs[4] at its per-GPU size: 832x832, 4 images per GPU, stage 1, the locked backbone's conv10-52 in OCP
+    # e4m3 on the block-scaled MFMA (round 6; conv1-9 keep their bf16 fused launches), and the same step in bf16 beside it
     for key, dt in (("train_832_fp8", "fp8"), ("train_832_bf16", "bf16")):
         try:
             d = child(["--stage", "1", "--batch", "4", "--dtype", dt], size=832)
@@ -351,10 +354,12 @@ def secondary_measurements(args, dev):
                         "frac_of_mfma_peak": round(gf * d["value"] / 1e3 / MFMA_PEAK_TFLOPS, 4),
                         "loss_first": d["config"].get("loss_first"), "loss_last": d["config"].get("loss_last"),
                         "conv_tiles": d["config"].get("conv_tiles"), "process": "child",
-                        "role": ("BASELINE configs[4] at its per-GPU size as this package runs it: bf16 is the faster path here"
+                        "role": ("the same step with a bf16 backbone, for comparison"
                                  if dt == "bf16" else
-                                 "the e4m3 backbone OPTION (parity-tested forward of conv1-52): slower than bf16 at 4 images per GPU, "
-                                 "where the backbone is 28 % of the step and fixed-cost dominated (DESIGN.md section 8)")}
+                                 "BASELINE configs[4] at its per-GPU size: conv10-52 of the locked backbone in e4m3 on "
+                                 "v_mfma_scale_f32_16x16x128_f8f6f4 (unit scales), conv1-9 in their bf16 fused launches; the faster "
+                                 "path since round 6 (+2.8 % over bf16 here, +14.8 % on the B = 32 inference batch: "
+                                 "profiles/r06_fp8_mx_layers.txt); the backbone is 28 % of this step")}
         except Exception as e:
             out[key] = {"error": repr(e)[:200]}
     try:
@@ -365,6 +370,13 @@ def secondary_measurements(args, dev):
                                   "frac_of_mfma_peak": d["model_flops"]["frac_of_mfma_peak"], "process": "child"}
     except Exception as e:
         out["infer_b32_graph"] = {"error": repr(e)[:200]}
+    try:     # the same batch with the e4m3 backbone (conv10-52 on the block-scaled MFMA)
+        d = child(["--task", "infer", "--batch", "32", "--dtype", "fp8"])
+        out["infer_b32_graph_fp8"] = {"workload": d["config"]["workload"] + "_hipgraph (network + NMS + PS-RoI mask assembly)",
+                                      "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
+                                      "steps": d["steps"], "repeats": 5, "process": "child"}
+    except Exception as e:
+        out["infer_b32_graph_fp8"] = {"error": repr(e)[:200]}
     # BASELINE.json configs[0] on the GPU: one 576x576 image through network + detection filter + mask assembly (what
     # calculate_test_map.py:218 runs per test image); the CPU oracle's number for the same call is cpu_baseline.config1_forward
     try:

@@ -267,6 +267,13 @@ def enable_data_parallel(net, process_group=None, bucket_mb: float = 12.0, wire:
     if inlist is None:
         inlist = (os.environ.get("DISYOLO_DP_INLIST", "1") != "0" and net.device.type == "cuda"
                   and not getattr(net, "plan_only", False) and dist.get_backend(process_group) == "nccl")
+    # the in-launch batch norm (launches whose blocks wait for each other) is a single-GPU-process feature as shipped: beside RCCL's
+    # own persistent kernels, which wait for OTHER ranks, its residency argument has never been exercised on more than one GPU
+    # (no multi-GPU box in any round) -- more than one rank runs the separate batch-norm launches
+    if dist.get_world_size(process_group) > 1 and getattr(net, "bn_inkernel", False) and not getattr(net, "plan_only", False):
+        net.bn_inkernel = False
+        if any(l.fused_fwd for l in net.layers):
+            net._apply_tiles()
     net.dp = GradientAllReduce(net, process_group, bucket_mb, wire, algo, inlist=inlist)
     if broadcast and net.dp.world_size > 1:
         broadcast_parameters(net, 0, process_group)

@@ -1774,8 +1774,16 @@ class YOLONet(object):
         that parity, produces the other)"""
         inl = self.dp is not None and self.dp.inlist
         if self.dp is not None and not inl:
-            # the RCCL all-reduces are issued on the side lane: keep it at normal stream priority
+            # the RCCL all-reduces are issued on the side lane: keep it at normal stream priority.  The lanes are streams of a
+            # process-wide pool whose priority is fixed when a lane is first used: the setting only helps if lane 1 does not
+            # exist yet -- say so when it is too late (a net that has recorded or tuned before enable_data_parallel)
             os.environ.setdefault("DISYOLO_LANE1_LOW", "0")
+            if not getattr(self, "plan_only", False):
+                for ln in L.lanes_report():
+                    if ln.startswith("lane 1:") and "priority 0," not in ln and os.environ.get("DISYOLO_LANE1_LOW") == "0":
+                        print("disyolo: the cut-list data-parallel step wants lane 1 at normal priority, but the lane already exists "
+                              "(%s): its bucket all-reduces queue behind a lowest-priority stream -- enable data parallelism before "
+                              "anything records or tunes, or use the in-list exchange (RCCL process group)" % ln, file=sys.stderr)
         prog = L.CmdList()
         marks = []
         if self.sync_bn and parity is not None:

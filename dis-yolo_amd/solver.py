@@ -159,16 +159,31 @@ class Solver(object):
             net.build_program(det_thresh=cfg.OBJ_THRESHOLD, overlap_tail=overlap)
         history = []
         first_pending = net.step_count       # the ring index of the first step whose loss has not been fetched yet
+        first_step_count = first_pending
         n_pending = 0
         train_timer.tic()
+
+        load_in_block = [0.0]      # data-loading seconds inside the block train_timer is timing (load_timer counts them too)
 
         def fetch():
             """the losses of the steps run since the last fetch: accumulated one by one, in order, like :218"""
             nonlocal epoch_loss, first_pending, n_pending
             if n_pending:
-                for v in net.step_losses(first_pending, n_pending):       # (joins the device)
+                if net.n_params == 0:
+                    vals = [float(net.total_loss().cpu())] * n_pending      # (nothing trainable: no optimizer finish files a loss)
+                else:
+                    vals = net.step_losses(first_pending, n_pending)        # (joins the device)
+                for i, v in enumerate(vals):
+                    if not np.isfinite(v):
+                        # a diverged run is reported at the first fetch that sees it, with the step it started at
+                        raise L.DisyoloError("non-finite total loss at step %d (fetched at step %d)"
+                                             % (self.start_iter + first_pending + i - first_step_count, self.global_step))
                     epoch_loss += float(v)
                     history.append(float(v))
+                # the block's wall time minus what it spent loading data: speed and load stay separate figures, like
+                # train_yolo3_mask.py:143-195's two timers
+                train_timer._sum -= load_in_block[0]
+                load_in_block[0] = 0.0
                 train_timer.toc(n_pending)
                 first_pending += n_pending
                 n_pending = 0
@@ -187,6 +202,7 @@ class Solver(object):
             else:
                 feed = self._next_feed()
             load_timer.toc()
+            load_in_block[0] += time.perf_counter() - load_timer._t0
             net.train_step(feed, det_thresh=cfg.OBJ_THRESHOLD, want_loss=False)
             n_pending += 1
             self.global_step += 1

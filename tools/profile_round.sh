@@ -9,7 +9,7 @@ cp /tmp/ps/*/*kernel_stats.csv $O/${TAG}_bench_stage1_kernel_stats.csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -- python3 $R/bench.py --no-cpu-baseline --no-secondary --no-box > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw -- python3 $R/bench.py --no-cpu-baseline --no-secondary --no-box > /dev/null 2>&1
 python3 $R/tools/make_pmc_traffic.py /tmp/pf/*/*counter_collection.csv /tmp/pw/*/*counter_collection.csv $O/${TAG}_pmc_traffic.json "$LABEL"
-cp $O/${TAG}_pmc_traffic.json $R/profiles/r05_pmc_traffic.json
+cp $O/${TAG}_pmc_traffic.json $R/profiles/r06_pmc_traffic.json     # (so that the bench line below already reads this round's traffic)
 cd $R
 python bench.py > $O/${TAG}_bench_stage1.json 2> $O/${TAG}_bench_err.txt
 tail -c 4000 $O/${TAG}_bench_stage1.json
