@@ -343,6 +343,16 @@ def secondary_measurements(args, dev):
                                                  "conv_tiles": d["config"].get("conv_tiles"), "process": "child"}
         except Exception as e:
             out["train_stage1_backbone_pair"] = {"error": repr(e)[:200]}
+    # the headline workload with the e4m3 backbone (NOT the headline: BASELINE.json's metric is bf16)
+    if args.stage == 1 and args.dtype == "bf16":
+        try:
+            d = child(["--stage", "1", "--batch", str(args.batch), "--dtype", "fp8"])
+            out["train_stage1_fp8_backbone"] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
+                                                "ms_per_step": d["ms_per_step"], "steps": d["steps"], "repeats": d.get("repeats"),
+                                                "dtype": d["dtype"], "loss_first": d["config"].get("loss_first"),
+                                                "loss_last": d["config"].get("loss_last"), "process": "child"}
+        except Exception as e:
+            out["train_stage1_fp8_backbone"] = {"error": repr(e)[:200]}
     # BASELINE.json configs[4] at its per-GPU size: 832x832, 4 images per GPU, stage 1, the locked backbone's conv10-52 in OCP
     # e4m3 on the block-scaled MFMA (round 6; conv1-9 keep their bf16 fused launches), and the same step in bf16 beside it
     for key, dt in (("train_832_fp8", "fp8"), ("train_832_bf16", "bf16")):
