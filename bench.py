@@ -662,6 +662,7 @@ def main():
             dist.all_reduce(ones)
         torch.cuda.synchronize()
         dp_trace["ranks_seen_by_rccl"] = int(round(float(ones[0].cpu())))
+    net.check_cluster_sync()       # (an in-launch exchange that timed out anywhere in the run: fail, do not report a throughput)
     finite = bool(np.all(np.isfinite(loss_trace))) and bool(torch.isfinite(net.arena).all())
     if world > 1:
         f = torch.tensor([1.0 if finite else 0.0], device=dev)

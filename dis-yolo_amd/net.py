@@ -1216,6 +1216,18 @@ class YOLONet(object):
             tgt.fused_bwd = True
         L.conv2d_fwd(d)
 
+    def check_cluster_sync(self) -> None:
+        """raise if a bounded wait of an in-launch exchange ever gave up (its launch then ran on with wrong sums): call at a
+        synchronisation point -- bench.py does after its timed regions, Solver at every loss fetch"""
+        for l in self.layers:
+            for name, buf in (("forward", l.csync), ("backward", l.csync_bwd)):
+                if buf is not None:
+                    code = L.cluster_sync_error(buf, l.cout)
+                    if code:
+                        raise L.DisyoloError("conv%d: the in-launch batch-norm exchange (%s) timed out (code %#x): another launch of "
+                                             "that kind was running on this device, or the grid was not resident; the results of "
+                                             "this run are wrong (DISYOLO_BN_INKERNEL=0 switches the feature off)" % (l.idx, name, code))
+
     def _shortcut_feeds_grad(self, tgt: Layer) -> bool:
         """tgt is a residual layer whose output gradient also goes to its shortcut's source (res_conv_bn): that copy rides
         on the separate batch-norm backward's apply pass"""

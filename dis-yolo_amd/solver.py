@@ -163,6 +163,7 @@ class Solver(object):
         n_pending = 0
         train_timer.tic()
 
+        nonfinite_seen = [False]
         load_in_block = [0.0]      # data-loading seconds inside the block train_timer is timing (load_timer counts them too)
 
         def fetch():
@@ -173,11 +174,15 @@ class Solver(object):
                     vals = [float(net.total_loss().cpu())] * n_pending      # (nothing trainable: no optimizer finish files a loss)
                 else:
                     vals = net.step_losses(first_pending, n_pending)        # (joins the device)
+                net.check_cluster_sync()
                 for i, v in enumerate(vals):
-                    if not np.isfinite(v):
-                        # a diverged run is reported at the first fetch that sees it, with the step it started at
-                        raise L.DisyoloError("non-finite total loss at step %d (fetched at step %d)"
-                                             % (self.start_iter + first_pending + i - first_step_count, self.global_step))
+                    if not np.isfinite(v) and not nonfinite_seen[0]:
+                        # reported at the first fetch that sees it, with the step it happened at -- reported, not raised: a step
+                        # whose mask loss meets a zero-area positive RoI IS NaN in the reference too, and the
+                        # reference keeps training through it
+                        nonfinite_seen[0] = True
+                        self.log("non-finite total loss at step %d (noticed at step %d, when the losses were fetched)"
+                                 % (self.start_iter + first_pending + i - first_step_count, self.global_step))
                     epoch_loss += float(v)
                     history.append(float(v))
                 # the block's wall time minus what it spent loading data: speed and load stay separate figures, like
