@@ -343,6 +343,16 @@ def secondary_measurements(args, dev):
                                                  "conv_tiles": d["config"].get("conv_tiles"), "process": "child"}
         except Exception as e:
             out["train_stage1_backbone_pair"] = {"error": repr(e)[:200]}
+    # the step of rounds 1-5 (no backbone pipeline; the side lane's tail overlapped with the next replay's backbone) for continuity
+    if args.stage == 1 and args.dtype == "bf16":
+        try:
+            d = child(["--stage", "1", "--batch", str(args.batch), "--pipeline", "off"])
+            out["train_stage1_plain_step"] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
+                                              "ms_per_step": d["ms_per_step"], "steps": d["steps"], "repeats": d.get("repeats"),
+                                              "what": "the same step without the backbone pipeline (the headline form of rounds 1-5)",
+                                              "step_overlap": bool(d["config"].get("step_overlap")), "process": "child"}
+        except Exception as e:
+            out["train_stage1_plain_step"] = {"error": repr(e)[:200]}
     # the headline workload with the e4m3 backbone (NOT the headline: BASELINE.json's metric is bf16)
     if args.stage == 1 and args.dtype == "bf16":
         try:
@@ -368,8 +378,7 @@ def secondary_measurements(args, dev):
                                  if dt == "bf16" else
                                  "BASELINE configs[4] at its per-GPU size: conv10-52 of the locked backbone in e4m3 on "
                                  "v_mfma_scale_f32_16x16x128_f8f6f4 (unit scales), conv1-9 in their bf16 fused launches; the faster "
-                                 "path since round 6 (+2.8 % over bf16 here, +14.8 % on the B = 32 inference batch: "
-                                 "profiles/r06_fp8_mx_layers.txt); the backbone is 28 % of this step")}
+                                 "path since round 6 (profiles/r06_fp8_mx_layers.txt, r06_backbone_pipeline.txt)")}
         except Exception as e:
             out[key] = {"error": repr(e)[:200]}
     try:
@@ -477,7 +486,7 @@ def main():
     ap.add_argument("--pipeline", default="auto", choices=("auto", "on", "off"),
                     help="cross-step software pipeline of the locked backbone (stage 1): each step computes the "
                          "backbone forward of the NEXT batch on a third lane while it runs heads/losses/backward/Adam "
-                         "of the current one (bit-identical results, but measured slower: auto = off)")
+                         "of the current one (bit-identical results; +5.9 % since round 6: auto = on in stage 1)")
     ap.add_argument("--autotune", default="on", choices=("on", "off"),
                     help="time the conv tile candidates inside the layer sequence before recording the step "
                          "(setup, outside the timed region)")
@@ -590,9 +599,16 @@ def main():
             hb = synthetic_batch(B, S, seed=1234 + rank + 7000 * q)
             feed_sets.append({k: (torch.as_tensor(v).to(dev) if v is not None else None) for k, v in hb.items()})
 
+    pipe_on = [False]          # set below, once the step has been recorded
+
     def step():
         if feed_sets is not None:
-            net.set_batch(feed_sets[n_trained[0] & 1])
+            cur = feed_sets[n_trained[0] & 1]
+            if pipe_on[0]:
+                # the pipelined step: the labels of THIS step's batch, the images of the NEXT one (whose backbone pass it runs)
+                cur = dict(cur)
+                cur["images"] = feed_sets[(n_trained[0] + 1) & 1]["images"]
+            net.set_batch(cur)
         net.train_step(None, want_loss=False)
         n_trained[0] += 1
 
@@ -610,11 +626,16 @@ def main():
             step()
         torch.cuda.synchronize()
         L.TIMER = None
-    # measured: the third lane's big conv kernels contend with the backward pass instead of filling
-    # its bubbles (958-1387 vs 1404 img/s without), so "auto" leaves the pipeline off
-    pipe = args.stage == 1 and mode == "program" and args.pipeline == "on"
+    # Rounds 1-3 measured the pipelined step SLOWER (958-1387 vs 1404 img/s) and "auto" left it off.  Round 6 measured it again, with
+    # round 5's lanes (streams chosen by measuring how their hardware queues behave beside each other): 2106 vs 1988 img/s, +5.9 %
+    # (profiles/r06_backbone_pipeline.txt) -- the third lane's locked-backbone convs fill what the backward pass leaves of the
+    # CUs.  Same kernels, same arithmetic, bit-identical variables (tests/test_gpu_net.py::test_pipelined_backbone_step_equals_
+    # plain_step); every timed step still passes ONE batch through the backbone and ONE through everything else.  "auto" = on where
+    # it applies: stage 1 (a locked prefix), the list executor, no --pair.
+    pipe = (args.stage == 1 and mode == "program" and not args.pair and args.pipeline in ("on", "auto")
+            and os.environ.get("DISYOLO_SIDE_LANE", "1") != "0")
     if args.pipeline == "on" and not pipe:
-        raise SystemExit("--pipeline on needs --stage 1 and --mode program")
+        raise SystemExit("--pipeline on needs --stage 1, --mode program and no --pair")
     overlap = (args.overlap_tail != "off" and mode == "program" and (not use_dp or net.dp.inlist) and not args.pair and not pipe
                and os.environ.get("DISYOLO_SIDE_LANE", "1") != "0")
     if args.overlap_tail == "on" and not overlap:
@@ -622,7 +643,10 @@ def main():
     if mode != "eager":
         net.build_program(graph=(mode == "graph"), pipeline_backbone=pipe, overlap_tail=overlap)
         if pipe:
+            if feed_sets is not None:
+                net._set_inputs(feed_sets[0]["images"], feed_sets[0]["clip_window"])
             net.prime_pipeline()       # backbone of the first batch, outside the timed region
+            pipe_on[0] = True
     if args.poison:
         net.arena[net.n_decay // 2] = float("nan")
         net.refresh_weights()
@@ -689,7 +713,11 @@ def main():
                        "parallelism": "dp%d%s" % (world, "+syncbn" if (use_dp and args.sync_bn) else ""), "rccl_buckets": ((len(net.opt_chunks) if net.dp.inlist else len(net.dp.buckets)) + 1) if net.dp else 0, "optimizer": "adam(tf-form) lr=1e-4", "step_driver": mode,
                        "conv_tiles": ("table %s" % os.path.relpath(cache, ROOT)) if cache else
                                      ("autotuned in-sequence at setup" if args.autotune == "on" else "launcher heuristic"),
-                       "backbone_pipeline": bool(args.stage == 1 and mode == "program" and args.pipeline == "on"),
+                       "backbone_pipeline": ("every step runs the locked backbone (conv1-52) of the NEXT batch on a third lane while it runs heads, "
+                                             "losses, backward and Adam of the current one (outputs double-buffered; the first batch's "
+                                             "backbone pass is primed before the timed regions, the last step's pass is for the batch after "
+                                             "them: K steps = K backbone passes + K trainable passes); bit-identical to the plain step")
+                                            if pipe else False,
                        "step_overlap": ("the side lane's tail of step t (last optimizer sweeps + re-pack, last weight gradients) runs into "
                                         "the locked-backbone forward of step t+1, per-tensor dependencies; bit-identical to the joined step")
                                        if overlap else False,

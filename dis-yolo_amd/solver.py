@@ -77,7 +77,8 @@ class Solver(object):
     def __init__(self, net, data, evalu=None, val_data=None, output_dir: Optional[str] = None,
                  lr_schedule: str = "faithful", restore_weight: Optional[str] = None, stage: int = 1,
                  max_iter: Optional[int] = None, summary_iter: Optional[int] = None, save_iter: Optional[int] = None,
-                 log: Callable[[str], None] = print, use_program: bool = True, shuffle_seed: Optional[int] = 20190530):
+                 log: Callable[[str], None] = print, use_program: bool = True, shuffle_seed: Optional[int] = 20190530,
+                 pipeline_backbone: Optional[bool] = None):
         """net: YOLONet(training=True); data: object with ``get()`` -> (images, true_masks, true_boxes, yolo_3,
         yolo_2, yolo_1, window) and attributes epoch / image_size / batch_size (utils/train_data.py:44-276);
         evalu: ``MAP``; val_data: object with ``get()`` -> (images [N,S,S,3], image ids, windows [N,4])
@@ -100,6 +101,10 @@ class Solver(object):
         self.learning_rate = 1e-4                 # :38 -- what the optimizer uses in "faithful" mode
         self.log = log
         self.use_program = use_program
+        # stage 1: the locked backbone of the NEXT batch runs on a third lane while the heads / losses / backward / Adam of the
+        # current one run (YOLONet.build_program(pipeline_backbone=True): bit-identical variables, +5.9 % on one MI355X) -- the
+        # loop then reads its data one batch ahead.  None = on where it applies (a locked prefix, the list executor, no pair).
+        self.pipeline_backbone = pipeline_backbone
         self.global_step = 0
         # tf.random_shuffle of the mask-loss RoIs every step (yolo/yolo3_net_pos.py:781-782): on the device, seeded
         # (a net that already has a seed -- or injected permutations with shuffle_seed=None -- keeps it)
@@ -151,12 +156,29 @@ class Solver(object):
         val_map = np.zeros((800, 9))
         epoch_loss = 0.0
         net = self.net
+        pipe = False
         if self.use_program and net._prog is None:
             net.set_batch(self._feed_peek())
             if getattr(net, "pair", False):
                 net.set_batch(self._pending, 1)      # (placeholder inputs while the two lists are recorded)
-            overlap = (net.use_side_lane and not getattr(net, "pair", False) and (net.dp is None or net.dp.inlist))
-            net.build_program(det_thresh=cfg.OBJ_THRESHOLD, overlap_tail=overlap)
+            pipe = self.pipeline_backbone
+            if pipe is None:
+                pipe = (net.use_side_lane and not getattr(net, "pair", False) and net._backbone_prefix() >= 2
+                        and net.dtype == "bf16" and not getattr(net, "sync_bn", False))
+            overlap = (not pipe and net.use_side_lane and not getattr(net, "pair", False) and (net.dp is None or net.dp.inlist))
+            net.build_program(det_thresh=cfg.OBJ_THRESHOLD, overlap_tail=overlap, pipeline_backbone=bool(pipe))
+        elif self.use_program:
+            pipe = getattr(net, "_progs", None) is not None and not getattr(net, "pair", False)      # (the caller recorded the step)
+        ahead = None
+
+        def prime():
+            """(re)compute the backbone pass of the batch the next step trains on: at the start, and after anything that ran
+            another forward pass through the net's buffers (the validation sweep)"""
+            net._set_inputs(ahead["images"], ahead["clip_window"])
+            net.prime_pipeline()
+        if pipe and self.start_iter <= self.max_iter:
+            ahead = self._next_feed()
+            prime()
         history = []
         first_pending = net.step_count       # the ring index of the first step whose loss has not been fetched yet
         first_step_count = first_pending
@@ -204,6 +226,13 @@ class Solver(object):
                 # backbone_pair: the even step takes its own batch and the next one (the locked backbone runs on both),
                 # the odd step takes nothing
                 feed = (self._next_feed(), self._next_feed()) if net._parity_now() == 0 else None
+            elif pipe:
+                # the labels of this step's batch, the images of the next one (whose backbone pass this step runs beside its own
+                # heads / backward); one batch is read ahead -- the batches a step trains on are the reference's, in its order
+                nxt = self._feed()
+                feed = dict(ahead)
+                feed["images"] = nxt["images"]
+                ahead = nxt
             else:
                 feed = self._next_feed()
             load_timer.toc()
@@ -221,6 +250,8 @@ class Solver(object):
                 self.events.flush()
                 if step % (self.summary_iter * 10) == 0 and self.eval is not None and self.val_data is not None:
                     thresh_out = self.validate()
+                    if pipe and step < self.max_iter:
+                        prime()          # (the sweep ran its images through the backbone's buffers)
                     record_loss = epoch_loss / self.save_iter
                     row = int(step / (self.summary_iter * 10)) - 1
                     if row < val_map.shape[0]:
