@@ -205,7 +205,10 @@ static bool pool_lane(int i, hipStream_t caller = nullptr) {
   const char* l1 = getenv("DISYOLO_LANE1_LOW");
   const bool lane1_low = !(l1 && l1[0] == '0');
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;   // no device (CPU-only build check)
-  const bool low = (i == 2 && getenv("DISYOLO_LANE2_LOW")) || (i == 1 && lane1_low) || (i == 3 && !(getenv("DISYOLO_LANE3_LOW") && getenv("DISYOLO_LANE3_LOW")[0] == '0'));
+  // lane 2 (the pipelined step's next-batch backbone): lowest priority as well since round 6 (+1.2 ... +1.5 % on the pipelined step;
+  // DISYOLO_LANE2_LOW=0: normal)
+  const bool lane2_low = !(getenv("DISYOLO_LANE2_LOW") && getenv("DISYOLO_LANE2_LOW")[0] == '0');
+  const bool low = (i == 2 && lane2_low) || (i == 1 && lane1_low) || (i == 3 && !(getenv("DISYOLO_LANE3_LOW") && getenv("DISYOLO_LANE3_LOW")[0] == '0'));
   const int prio = low ? least : 0;
   rep.priority = prio;
 #ifndef DY_HOST_ONLY

@@ -1302,20 +1302,24 @@ class YOLONet(object):
                         L.lane_wait(mark, 1)
                         waited = True
                     L.set_lane(1)
+                # scratch of the lane the gradient runs on: the side lane's weight gradients own ws_aux; one kept on the main lane
+                # (tail_on_main) must not share it -- the side lane may still be inside an earlier layer's slabs (found in round 6:
+                # with DISYOLO_TAIL_MAIN > 0 the loss differed from run to run)
+                wsl = self.ws_aux if pside else self.ws
                 if pl.kind == "lin":
-                    L.colsum(pl.dx, pl.dbias, pM, L.GRAD_LD, pl.cout, self.ws_aux)   # bias gradient
+                    L.colsum(pl.dx, pl.dbias, pM, L.GRAD_LD, pl.cout, wsl)   # bias gradient
                 if pl.idx == 1:
                     if pl.cout == 32 and os.environ.get("DISYOLO_FIRST_WGRAD_MFMA", "1") != "0":
                         # the first layer's own kernel: taps as the M axis of the MFMA, the f32 image rounded to bf16 on
                         # its way into LDS (csrc/conv_wgrad.hip, conv_first_wgrad_mfma_kernel)
-                        L.conv_first_wgrad(self.images, pl.dx, pl.dw, self.ws_aux)
+                        L.conv_first_wgrad(self.images, pl.dx, pl.dw, wsl)
                     else:
                         # through the im2col kernel: bf16 image padded to 8 channels, K = 9*8 rows of which 27 are real
                         L.image_pad8(self.images, self._img8)
-                        L.conv2d_wgrad(self._wgrad1_desc, pl.dx, pl.cout, self._dw8, self.ws_aux)
+                        L.conv2d_wgrad(self._wgrad1_desc, pl.dx, pl.cout, self._dw8, wsl)
                         L.copy2d_f32(self._dw8, pl.dw, 9, 3 * pl.cout, 8 * pl.cout, 3 * pl.cout)
                 elif os.environ.get("DISYOLO_EXP_SKIP_WGRAD") not in ("1", "2"):     # (experiment: the step without its weight gradients)
-                    L.conv2d_wgrad(pl.wgrad_desc, pdx, pld, pl.dw, self.ws_aux)
+                    L.conv2d_wgrad(pl.wgrad_desc, pdx, pld, pl.dw, wsl)
                 if pside:
                     L.set_lane(0)
                 if self._overlap_rec:
@@ -1742,6 +1746,11 @@ class YOLONet(object):
         if pipeline_backbone:
             if graph:
                 raise L.DisyoloError("pipeline_backbone uses the list executor, not a hipGraph")
+            if "DISYOLO_TAIL_MAIN" not in os.environ and self.dp is None:
+                # the pipelined step joins its lanes at the end of every replay: the weight gradients of the LAST two layers of
+                # the backward pass stay on the main lane, which would only wait for them (tail 0 / 1 / 2 / 3 / 4 / 6 / 8 layers:
+                # 3.82 / 3.80 / 3.76 / 3.76 / 3.81 / 3.85 / 3.94 ms per step, profiles/r06_backbone_pipeline.txt)
+                self.tail_on_main = 2
             self._setup_pipeline()
             self._progs = []
             for q in (0, 1):
@@ -1808,10 +1817,10 @@ class YOLONet(object):
                 first = self._pipe_P + 1
             if self.pair and self._half == 1:
                 first = self._pair_P + 1         # (the even step ran the backbone for this half too)
-            self.compute_losses(det_thresh, first)
-            if parity is not None:
-                # the next batch's backbone: lowest-priority lane, started once the trunk's forward
-                # is done, so it fills the bubbles of the latency-bound backward chain
+            pipe_early = parity is not None and os.environ.get("DISYOLO_PIPE_EARLY", "0") == "1"
+
+            def next_backbone():
+                # the next batch's backbone: lowest-priority lane (lane 2)
                 self._use_parity(1 - parity)
                 lane = int(os.environ.get("DISYOLO_PIPE_LANE", "2"))
                 L.lane_sync(0, lane)
@@ -1819,6 +1828,12 @@ class YOLONet(object):
                 self._forward_prefix(self._pipe_P, True)
                 L.set_lane(0)
                 self._use_parity(parity)
+            if pipe_early:
+                next_backbone()      # (experiment: from the start of the step, beside the heads' forward pass as well)
+            self.compute_losses(det_thresh, first)
+            if parity is not None and not pipe_early:
+                # ... started once the trunk's forward is done, so it fills what the backward pass leaves of the CUs
+                next_backbone()
             if self.dp is not None and not inl:
                 self.dp.begin_step()
 
