@@ -28,6 +28,7 @@ ap.add_argument("--ab", default=None, help="'<key json>=<cand>,<cand>,...': inte
 ap.add_argument("--compare", default=None, help="another table (or sweep output): interleaved rounds of --table and this one")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--start", type=int, default=0, help="resume at this key index (keys are ordered by size)")
+ap.add_argument("--plain", action="store_true", help="stage 1: sweep inside the plain (overlapped-tail) step instead of the pipelined one")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 B, S = args.batch, args.size
@@ -64,7 +65,13 @@ def rebuild():
     L.TUNED.clear()
     L.TUNED.update({k: v for k, v in table.items() if v})
     net._apply_tiles()
-    net.build_program(overlap_tail=True)
+    net._progs = None
+    if args.stage == 1 and not args.plain:
+        # round 6: the step bench.py and Solver run in stage 1 is the PIPELINED one (next batch's backbone on the third lane)
+        net.build_program(pipeline_backbone=True)
+        net.prime_pipeline()
+    else:
+        net.build_program(overlap_tail=True)
 
 
 def measure(reps=3):
