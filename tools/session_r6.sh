@@ -110,4 +110,166 @@ call16() {
   for v in 1 0; do DISYOLO_HALO_SPLIT_ROWS=$v CC_ONLY=halo timeout 200 python tools/conv_counters.py run 2>&1 | grep CASE; done
 }
 
+call17() {
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*'[:70], '|', d['config']['workload'], d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'), d['config'].get('bn_inkernel',{}).get('forward_layers'))
+"; }
+C="--no-secondary --no-cpu-baseline --no-box"
+for r in 1 2; do
+b DISYOLO_BN_INKERNEL_ROW_KB=128 timeout 300 python bench.py $C
+b DISYOLO_BN_INKERNEL_ROW_KB=256 timeout 300 python bench.py $C
+b DISYOLO_BN_INKERNEL=0 timeout 300 python bench.py $C
+b DISYOLO_BN_INKERNEL=1 timeout 300 python bench.py $C --stage 2 --steps 10 --repeats 5
+b DISYOLO_BN_INKERNEL=0 timeout 300 python bench.py $C --stage 2 --steps 10 --repeats 5
+b DISYOLO_X=1 timeout 300 python bench.py $C --dtype fp8
+done
+}
+
+call22() {
+timeout 900 python tools/instep_sweep.py --stage 2 --steps 20 --table profiles/tune_train_B8_576_stage2.json --compare profiles/tune_train_B8_576_stage2_r06cand.json --rounds 4 > $O/r06_sweep2_compare.txt 2>&1; tail -3 $O/r06_sweep2_compare.txt | cut -c1-300
+cd /tmp; export TMPDIR=/tmp
+rm -rf /tmp/pmc_step
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d /tmp/pmc_step -- python3 $R/bench.py --no-secondary --no-cpu-baseline --no-box --no-kernel-events --steps 10 --repeats 2 > /dev/null 2>&1
+python3 - <<'PY'
+import csv, glob, re, collections, os
+f = glob.glob('/tmp/pmc_step/**/*counter_collection.csv', recursive=True)[0]
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
+for r in csv.DictReader(open(f)):
+    name = re.sub(r"\(anonymous namespace\)::|void |dyconv::|HIP_vector_type<[^>]*>|\(.*$", "", r["Kernel_Name"])
+    acc[name][r["Counter_Name"]] += float(r["Counter_Value"]); n[name].add(r["Dispatch_Id"])
+out = open(os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/r06_step_sq_counters.txt", "w")
+hdr = "%-52s %6s %11s %7s %7s %7s %9s %9s %9s" % ("kernel", "launch", "wavecyc/l", "parked", "stalled", "issuing", "mfma/wave", "lds_act/w", "lds_cnfl/w")
+print(hdr); out.write(hdr + "\n")
+for name, c in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:30]:
+    k = len(n[name]); wc = c["SQ_WAVE_CYCLES"] or 1
+    line = "%-52s %6d %11.0f %6.1f%% %6.1f%% %6.1f%% %8.2f%% %8.2f%% %8.2f%%" % (name[:52], k, wc / k, 100 * c["SQ_WAIT_ANY"] / wc, 100 * c["SQ_WAIT_INST_ANY"] / wc,
+        100 * c["SQ_ACTIVE_INST_ANY"] / wc, 100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * wc), 100 * c["SQ_LDS_IDX_ACTIVE"] / (4 * wc), 100 * c["SQ_LDS_BANK_CONFLICT"] / (4 * wc))
+    print(line); out.write(line + "\n")
+PY
+}
+
+call28() {
+timeout 1200 python -m pytest tests/test_gpu_drivers.py tests/test_gpu_train_data.py tests/test_gpu_net.py -x -q > $O/r06k_tests.txt 2>&1; echo "tests rc=$?"; tail -4 $O/r06k_tests.txt
+b() { "$@" 2>$O/r06k_err.txt | python3 -c "
+import sys, json
+try:
+    d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+    print('$*'[-60:], '|', d['config']['workload'], d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'), 'pipe' if d['config'].get('backbone_pipeline') else 'plain', d['config'].get('loss_last'))
+except Exception as e:
+    print('$*', 'FAILED', e); print(open('$O/r06k_err.txt').read()[-1500:])
+"; }
+C="--no-secondary --no-cpu-baseline --no-box --no-kernel-events"
+for r in 1 2; do
+b timeout 300 python bench.py $C
+b timeout 300 python bench.py $C --pipeline off
+b timeout 300 python bench.py $C --feed per-step
+b timeout 300 python bench.py $C --feed per-step --pipeline off
+done
+b timeout 300 python bench.py $C --dtype fp8
+b timeout 300 python bench.py $C --dtype fp8 --pipeline off
+b timeout 300 python bench.py $C --size 832 --batch 4 --steps 10 --repeats 5
+b timeout 300 python bench.py $C --size 832 --batch 4 --steps 10 --repeats 5 --dtype fp8
+b timeout 300 python bench.py $C --force-dp
+}
+
+call29() {
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*'[:58], '|', d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'))
+"; }
+C="--no-secondary --no-cpu-baseline --no-box --no-kernel-events"
+for r in 1 2; do
+b A=1 timeout 300 python bench.py $C
+b DISYOLO_LANE2_LOW=1 timeout 300 python bench.py $C
+b DISYOLO_BN_INKERNEL=0 timeout 300 python bench.py $C
+b DISYOLO_WG3_BLOCKS=160 DISYOLO_WG_BLOCKS=160 timeout 300 python bench.py $C
+b DISYOLO_WG3_BLOCKS=224 DISYOLO_WG_BLOCKS=224 timeout 300 python bench.py $C
+b DISYOLO_WG3_BLOCKS=256 DISYOLO_WG_BLOCKS=256 timeout 300 python bench.py $C
+b DISYOLO_WGRAD_GROUP=2 timeout 300 python bench.py $C
+b DISYOLO_WGRAD_GROUP=4 timeout 300 python bench.py $C
+b DISYOLO_HALO_SPLIT_ROWS=0 timeout 300 python bench.py $C
+done
+}
+
+call30() {
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*'[:64], '|', d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'))
+"; }
+C="--no-secondary --no-cpu-baseline --no-box --no-kernel-events"
+for r in 1 2 3; do
+b DISYOLO_LANE2_LOW=1 timeout 300 python bench.py $C
+b DISYOLO_LANE2_LOW=1 DISYOLO_WGRAD_GROUP=2 timeout 300 python bench.py $C
+b DISYOLO_LANE2_LOW=1 DISYOLO_WGRAD_GROUP=1 timeout 300 python bench.py $C
+b DISYOLO_LANE2_LOW=1 DISYOLO_LANE1_LOW=0 timeout 300 python bench.py $C
+b DISYOLO_LANE2_LOW=1 DISYOLO_BN_INKERNEL=0 timeout 300 python bench.py $C
+b DISYOLO_LANE2_LOW=1 DISYOLO_TAIL_MAIN=2 timeout 300 python bench.py $C
+done
+}
+
+call31() {
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*'[:60], '|', d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'))
+"; }
+C="--no-secondary --no-cpu-baseline --no-box --no-kernel-events"
+for r in 1 2 3; do
+for t in 0 1 2 3 4 6 8; do
+b DISYOLO_LANE2_LOW=1 DISYOLO_TAIL_MAIN=$t timeout 300 python bench.py $C
+done
+done
+}
+
+call32() {
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*'[:84], '|', d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'), d['config'].get('loss_last'))
+"; }
+C="--no-secondary --no-cpu-baseline --no-box --no-kernel-events"
+for r in 1 2 3; do
+b DISYOLO_LANE2_LOW=1 DISYOLO_TAIL_MAIN=2 timeout 300 python bench.py $C
+b DISYOLO_LANE2_LOW=1 DISYOLO_TAIL_MAIN=2 DISYOLO_PIPE_EARLY=1 timeout 300 python bench.py $C
+b DISYOLO_LANE2_LOW=1 DISYOLO_TAIL_MAIN=3 DISYOLO_PIPE_EARLY=1 timeout 300 python bench.py $C
+b DISYOLO_TAIL_MAIN=2 DISYOLO_PIPE_EARLY=1 timeout 300 python bench.py $C
+done
+}
+
+call33() {
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*'[:70], '|', d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'), d['config'].get('loss_last'))
+"; }
+C="--no-secondary --no-cpu-baseline --no-box --no-kernel-events"
+for r in 1 2 3; do
+b A=1 timeout 300 python bench.py $C
+b DISYOLO_TAIL_MAIN=0 timeout 300 python bench.py $C
+b A=1 timeout 300 python bench.py $C --pipeline off
+done
+timeout 900 python -m pytest tests/test_gpu_net.py tests/test_gpu_drivers.py tests/test_gpu_configs.py -x -q 2>&1 | tail -3
+}
+
+call35() {
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*'[:70], '|', d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'), d['config'].get('loss_last'))
+"; }
+C="--no-secondary --no-cpu-baseline --no-box --no-kernel-events"
+for r in 1 2; do
+b A=1 timeout 300 python bench.py $C
+b DISYOLO_BN_INKERNEL_BWD=1 timeout 300 python bench.py $C
+b DISYOLO_BN_INKERNEL_ROW_KB=256 timeout 300 python bench.py $C
+b DISYOLO_OPT_CHUNK_M=4 timeout 300 python bench.py $C
+b DISYOLO_OPT_CHUNK_M=16 timeout 300 python bench.py $C
+done
+timeout 1500 python tools/instep_sweep.py --stage 1 --out gpurun_out/r06_sweep1p.json --budget 1000 > $O/r06_sweep1p.txt 2>&1; grep -E "^base|^final" $O/r06_sweep1p.txt
+}
+
 "$@"
