@@ -543,7 +543,10 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     constexpr int CPR8 = WTN / 8, CH = WTM * CPR8;
     bf16* yo = reinterpret_cast<bf16*>(p.y);
-    if constexpr (KG == 1 && EPI == 1) if (p.flags & DISYOLO_CONV_BN_BWD_FUSED) {
+    if constexpr (KG == 1 && EPI == 1) if (p.flags & DISYOLO_CONV_BN_BWD_STATS) {
+      // whole = DISYOLO_CONV_BN_BWD_FUSED; without it (DISYOLO_CONV_BN_BWD_STATS alone, as on the patch kernels) only pass 1
+      // runs: one row of partial sums per pixel tile for bn_act_bwd_partials, no exchange, y receives the gradient as usual
+      const bool whole = p.flags & DISYOLO_CONV_BN_BWD_FUSED;
       // ---- the target layer's whole batch-norm backward inside this data-gradient conv (DISYOLO_CONV_BN_BWD_FUSED): the
       //      staged tile is the (now final) gradient wrt the target's ACTIVATION, rounded to bf16 as the separate launches
       //      would have read it back.  Pass 1: this block's (sum g, sum g*xhat) per channel from the staged values and the
@@ -589,8 +592,22 @@ __global__ __launch_bounds__(WM* WN * 64 * KG, (BM == 128 && BN == 128) ? 3 : 1)
             s += red[(w_ * BN + nl) * 2 + 0];
             s2 += red[(w_ * BN + nl) * 2 + 1];
           }
-          cl_store2(p.bn_part + ((size_t)mt * p.Cout + n) * 2, s, s2);
+          if (whole)
+            cl_store2(p.bn_part + ((size_t)mt * p.Cout + n) * 2, s, s2);
+          else
+            bnpart_out(p, mt, n, s, s2);
         }
+      }
+      if (!whole) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+          const int idx = it * 64 + lane;
+          const int row = idx / CPR8;
+          const int m = m0 + wm * WTM + row;
+          if (idx < CH && m < Mlim && ncol < p.Cout)
+            *reinterpret_cast<uint4*>(yo + oaddr(m, ncol)) = *reinterpret_cast<const uint4*>(sw + row * ROWP + chl * 16);
+        }
+        return;
       }
       cl_arrive(p.csync, nt);
       double* dscr = reinterpret_cast<double*>(smem + ((WM * BN * 8 + BN * 8 + NW * (WTM * ROWP) + 15) & ~15));
@@ -2121,9 +2138,9 @@ int launch_ks(const ConvParams& p, hipStream_t s) {
     tl_query.resident = resident_blocks(&conv_igemm_kernel<BM, BN, WM, WN, BK, ST, KS, KG>, NW * 64 * KG, lds);
     return DISYOLO_OK;
   }
-  if (p.flags & DISYOLO_CONV_BN_BWD_FUSED) {
+  if (p.flags & (DISYOLO_CONV_BN_BWD_FUSED | DISYOLO_CONV_BN_BWD_STATS)) {
     if constexpr (HAS_BWD) {
-      DY_REQUIRE(q.pcls == 0, "conv: BN_BWD_FUSED on a parity-class data gradient");
+      DY_REQUIRE(q.pcls == 0 && p.d2s_c == 0, "conv: BN_BWD_STATS / BN_BWD_FUSED on a parity-class or depth-to-space data gradient");
       static bool attr1 = false;
       if (!attr1) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, ST, KS, KG, 1>),
@@ -2134,7 +2151,8 @@ int launch_ks(const ConvParams& p, hipStream_t s) {
       DY_CHECK_LAUNCH();
       return DISYOLO_OK;
     } else {
-      disyolo_set_error("conv: BN_BWD_FUSED on a GEMM tile without that epilogue (%dx%d, k %d; ask disyolo_conv2d_bn_fused_ok)", BM, BN, KS);
+      disyolo_set_error("conv: BN_BWD_STATS / BN_BWD_FUSED on a GEMM tile without that epilogue (%dx%d, k %d; ask disyolo_conv2d_bn_bwd_stats_ok / "
+                        "disyolo_conv2d_bn_fused_ok)", BM, BN, KS);
       return DISYOLO_E_ARG;
     }
   }
@@ -2289,8 +2307,22 @@ static int resolve_sel(const disyolo_conv_desc* d, int M, Patch* pt) {
 
 extern "C" int disyolo_conv2d_bn_bwd_stats_ok(const disyolo_conv_desc* d) {
   if (!d || (d->flags & DISYOLO_CONV_OUT_F32) || d->Cout % 8) return 0;
-  const int id = resolve_sel(d, d->B * d->Ho * d->Wo, nullptr) & 0xff;
-  return (id >= 16 && id < 20) || id == 24 || id == 25 ? 1 : 0;
+  const int sel = resolve_sel(d, d->B * d->Ho * d->Wo, nullptr);
+  int id = sel & 0xff;
+  if ((id >= 16 && id < 20) || id == 24 || id == 25) return 1;
+  if (!is_gemm_tile(id) || d->in_div != 1) return 0;
+  // round 6: the GEMM tiles that have an EPI = 1 instance (launch_ks: HAS_BWD) can emit the rows too, one per pixel tile --
+  // opt-in (DISYOLO_BN_BWD_STATS_GEMM=1): measured SLOWER in the step than the column reduction it replaces (19 -> 5 colreduce
+  // launches per stage-1 step, 3.63 -> 3.69 ms; stage 2 9.49 -> 9.58 ms; profiles/r06_bn_inkernel.txt): the epilogue's extra
+  // registers and its x-tile read at the end of every block cost the convs more than the HBM-bound sweeps cost beside them
+  {
+    const char* e = getenv("DISYOLO_BN_BWD_STATS_GEMM");
+    if (!(e && e[0] == '1')) return 0;
+  }
+  const bool bk64 = (d->C0 % 64 == 0) && (d->C1 % 64 == 0) && !(sel & 0x100);
+  id = resolve_tile(id, bk64, d->ksize * d->ksize * (d->C0 + d->C1));
+  if (id == 12) return 1;                                                                  // 192x128: 1x1 and 3x3
+  return d->ksize == 1 && (id == 1 || id == 2 || id == 3 || id == 6 || id == 9 || id == 10 || id == 11) ? 1 : 0;
 }
 
 extern "C" int disyolo_conv2d_stats_rows(const disyolo_conv_desc* d) {
@@ -2513,7 +2545,8 @@ static int conv2d_fwd_core(const disyolo_conv_desc* d, void* stream) {
     DY_REQUIRE(d->bn_x && d->bn_scale && d->bn_shift && d->bn_mean && d->bn_rstd && d->bn_partials,
                "conv: BN_BWD_STATS flag with a null bn_* pointer");
     DY_REQUIRE((d->flags & DISYOLO_CONV_BN_BWD_FUSED) || disyolo_conv2d_bn_bwd_stats_ok(d) == 1,
-               "conv: BN_BWD_STATS needs a patch kernel (tile 16-18, 24, 25 on a shape it covers), bf16 output, Cout %% 8 == 0");
+               "conv: BN_BWD_STATS needs a patch kernel (tile 16-19, 24, 25 on a shape it covers) or a GEMM tile with that epilogue "
+               "(ask disyolo_conv2d_bn_bwd_stats_ok), bf16 output, Cout %% 8 == 0");
     DY_REQUIRE(!(d->flags & DISYOLO_CONV_BN_BWD_FUSED) || (!(d->flags & (DISYOLO_CONV_OUT_F32 | DISYOLO_CONV_STATS | DISYOLO_CONV_LEAKY)) &&
                                                           !d->scale && !d->shift && d->Cout % 8 == 0),
                "conv: BN_BWD_FUSED needs a plain bf16 data-gradient conv (no scale / shift / LEAKY / STATS), Cout %% 8 == 0");

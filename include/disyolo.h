@@ -149,7 +149,8 @@ int disyolo_find_contours(const uint8_t* binary, int h, int w, int32_t* points_x
                           int64_t* n_points);
 /* sizeof(disyolo_conv_desc) as this library was built: a binding checks its mirror against it */
 size_t disyolo_conv_desc_size(void);
-/* 1 when a call with this descriptor runs a kernel that can emit DISYOLO_CONV_BN_BWD_STATS (the patch kernel) */
+/* 1 when a call with this descriptor runs a kernel that can emit DISYOLO_CONV_BN_BWD_STATS: the patch kernels and (round 6)
+ * the GEMM tiles that carry that epilogue (1x1: 64x64, 64x128, 128x64, 96x128, 128x128; 1x1 and 3x3: 192x128), in_div 1 */
 int disyolo_conv2d_bn_bwd_stats_ok(const disyolo_conv_desc* d);
 /* 1 when a call with this descriptor (shape and tile as given) can run batch norm inside the launch -- the backward form
  * when DISYOLO_CONV_BN_BWD_FUSED is set in its flags, the forward form otherwise (DISYOLO_CONV_BN_FUSED need not be set):

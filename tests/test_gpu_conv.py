@@ -761,6 +761,88 @@ def test_patch_conv_emits_batchnorm_backward_sums(dev, B, H, W, Cin, Cout, tile,
                                       bn_bwd=(bn_x.to(torch.bfloat16).to(dev), dev_t[0], dev_t[1], dev_t[2], dev_t[3], part, 0.1)))
 
 
+BN_BWD_GEMM_CASES = [
+    # B, H, W, Cin, Cout, k, tile, residual
+    (2, 18, 18, 128, 64, 1, 6, True),        # 64x64
+    (2, 18, 18, 128, 256, 1, 3, False),      # 64x128
+    (2, 18, 18, 128, 256, 1, 0x203, True),   # ... alternative pipeline depth
+    (2, 18, 18, 128, 64, 1, 2, True),        # 128x64
+    (2, 18, 18, 256, 128, 1, 1, False),      # 128x128
+    (2, 18, 18, 128, 128, 1, 10, True),      # 96x128: 648 pixels = 6.75 tiles (ragged last tile)
+    (2, 18, 18, 128, 128, 1, 11, False),     # 96x128, deep pipeline
+    (2, 18, 18, 128, 128, 1, 9, False),      # 64x128, deep pipeline
+    (2, 18, 18, 128, 72, 1, 6, True),        # ragged channel tile (72 = 64 + 8)
+    (2, 18, 18, 96, 128, 1, 3, False),       # BK = 32 (96 channels)
+    (3, 18, 18, 128, 256, 1, 12, True),      # 192x128 (972 pixels: 5.06 tiles)
+    (3, 18, 18, 128, 256, 1, 0x20c, False),  # 192x128, three stages
+    (2, 18, 18, 64, 128, 3, 12, True),       # 192x128 on a 3x3 layer
+    (1, 36, 36, 64, 256, 3, 0x20c, False),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,tile,with_res", BN_BWD_GEMM_CASES)
+def test_gemm_tile_conv_emits_batchnorm_backward_sums(dev, monkeypatch, B, H, W, Cin, Cout, k, tile, with_res):
+    """round 6: the GEMM tiles that carry the batch-norm backward epilogue (the EPI = 1 instances, conv_igemm.hip launch_ks
+    HAS_BWD) can emit DISYOLO_CONV_BN_BWD_STATS rows too, one per pixel tile -- what the data gradients of the 1x1 layers run, whose
+    targets' batch-norm backward needs a column reduction over (dy, x).  Opt-in (DISYOLO_BN_BWD_STATS_GEMM=1: measured slower in
+    the step, profiles/r06_bn_inkernel.txt).  Same statement as for the patch kernels: output unchanged bit for bit, rows summed =
+    the column reduction over the stored bf16 tensor."""
+    monkeypatch.setenv("DISYOLO_BN_BWD_STATS_GEMM", "1")
+    g = torch.Generator().manual_seed(B + H + Cin + Cout + tile + k)
+    x = bf16r(torch.randn(B, H, W, Cin, generator=g))
+    w = bf16r(torch.randn(k, k, Cin, Cout, generator=g) / (k * k * Cin) ** 0.5)
+    res = bf16r(torch.randn(B, H, W, Cout, generator=g)) if with_res else None
+    bn_x = bf16r(torch.randn(B, H, W, Cout, generator=g) * 2 + 0.3)
+    mean = torch.randn(Cout, generator=g) * 0.2 + 0.3
+    rstd = torch.rand(Cout, generator=g) + 0.3
+    scale = torch.randn(Cout, generator=g) * rstd
+    shift = torch.randn(Cout, generator=g) * 0.5 - mean * scale
+    xd, wd = x.to(torch.bfloat16).to(dev), pack_ref(w).to(torch.bfloat16).to(dev)
+    resd = res.to(torch.bfloat16).to(dev) if with_res else None
+    y0 = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=dev)
+    y1 = torch.full_like(y0, float("nan"))
+    plain = L.make_conv_desc(xd, wd, y0, k, 1, residual=resd, tile=tile)
+    assert L.conv2d_bn_bwd_stats_ok(plain)
+    L.conv2d_fwd(plain)
+    rows = L.conv2d_stats_rows(plain)
+    part = torch.full((rows, Cout, 2), float("nan"), device=dev)
+    dev_t = [t.to(dev) for t in (scale, shift, mean, rstd)]
+    L.conv2d_fwd(L.make_conv_desc(xd, wd, y1, k, 1, residual=resd, tile=tile,
+                                  bn_bwd=(bn_x.to(torch.bfloat16).to(dev), dev_t[0], dev_t[1], dev_t[2], dev_t[3], part, 0.1)))
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    assert torch.isfinite(part).all(), "a partial-sum row was not written"
+    dy = y1.double().cpu().reshape(-1, Cout)
+    vx = bn_x.reshape(-1, Cout)
+    z = vx * scale.double() + shift.double()
+    gg = dy * torch.where(z > 0, 1.0, 0.1)
+    xh = (vx - mean.double()) * rstd.double()
+    got = part.double().sum(0).cpu()
+    for q, term in ((0, gg), (1, gg * xh)):
+        want = term.sum(0)
+        tol = 1e-4 * term.abs().sum(0) + 1e-6
+        assert ((got[:, q] - want).abs() <= tol).all(), (q, float((got[:, q] - want).abs().max()))
+
+
+def test_gemm_tiles_without_the_epilogue_refuse_the_flag(dev, monkeypatch):
+    """a 3x3 conv on a tile other than 192x128 and the narrow tiles have no such epilogue, and no GEMM tile has it unless
+    DISYOLO_BN_BWD_STATS_GEMM=1: disyolo_conv2d_bn_bwd_stats_ok says so and the call with the flag raises"""
+    x = torch.zeros(2, 18, 18, 128, dtype=torch.bfloat16, device=dev)
+    assert not L.conv2d_bn_bwd_stats_ok(L.make_conv_desc(x, torch.zeros(128, 128, dtype=torch.bfloat16, device=dev), torch.zeros_like(x), 1, 1, tile=6))
+    monkeypatch.setenv("DISYOLO_BN_BWD_STATS_GEMM", "1")
+    x = torch.zeros(2, 18, 18, 128, dtype=torch.bfloat16, device=dev)
+    y = torch.zeros(2, 18, 18, 128, dtype=torch.bfloat16, device=dev)
+    w3 = torch.zeros(128, 9 * 128, dtype=torch.bfloat16, device=dev)
+    w1 = torch.zeros(128, 128, dtype=torch.bfloat16, device=dev)
+    assert not L.conv2d_bn_bwd_stats_ok(L.make_conv_desc(x, w3, y, 3, 1, tile=1))
+    assert not L.conv2d_bn_bwd_stats_ok(L.make_conv_desc(x, w1, y, 1, 1, tile=4))          # 128x32
+    assert L.conv2d_bn_bwd_stats_ok(L.make_conv_desc(x, w1, y, 1, 1, tile=6))
+    v = torch.zeros(128, device=dev)
+    part = torch.zeros(64, 128, 2, device=dev)
+    with pytest.raises(L.DisyoloError):
+        L.conv2d_fwd(L.make_conv_desc(x, w1, y, 1, 1, tile=4, bn_bwd=(y, v, v, v, v, part, 0.1)))
+
+
 def test_bn_act_bwd_from_conv_partials_matches_the_plain_path(dev):
     """bn_act_bwd_partials(partials of the patch conv) == bn_act_bwd(column reduction over dy, x) up to the f32
     summation order of the two reductions (dgamma / dbeta to 2e-5 of the sum of magnitudes; dx within one bf16 ulp)."""
