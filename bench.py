@@ -608,7 +608,8 @@ def main():
                 # the pipelined step: the labels of THIS step's batch, the images of the NEXT one (whose backbone pass it runs)
                 cur = dict(cur)
                 cur["images"] = feed_sets[(n_trained[0] + 1) & 1]["images"]
-            net.set_batch(cur)
+            with net.feed_context():     # (the pipelined step: on the net's feed stream, beside the replay that is running)
+                net.set_batch(cur)
         net.train_step(None, want_loss=False)
         n_trained[0] += 1
 
@@ -644,8 +645,9 @@ def main():
         net.build_program(graph=(mode == "graph"), pipeline_backbone=pipe, overlap_tail=overlap)
         if pipe:
             if feed_sets is not None:
-                net._set_inputs(feed_sets[0]["images"], feed_sets[0]["clip_window"])
-            net.prime_pipeline()       # backbone of the first batch, outside the timed region
+                net.prime_pipeline(feed_sets[0]["images"], feed_sets[0]["clip_window"])
+            else:
+                net.prime_pipeline()   # backbone of the first batch, outside the timed region
             pipe_on[0] = True
     if args.poison:
         net.arena[net.n_decay // 2] = float("nan")

@@ -651,18 +651,70 @@ class YOLONet(object):
                      if i is not None and 1 <= i <= P})
         self._xbuf = {i: (self.by_idx[i].act, torch.zeros_like(self.by_idx[i].act)) for i in xs}
         self._parity = 0
+        # the per-batch inputs, two sets: the list of parity q reads set q (labels / boxes / masks of its batch, images of the
+        # batch after it), so the feed of the NEXT replay can be written while this one runs (``feed_context``).  Set 1 starts
+        # as a copy of set 0: a batch set once before build_program is replayed by both lists.
+        first = {n: getattr(self, n) for n in self.PIPE_INPUTS}
+        second = {n: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for n, v in first.items()}
+        self._pipe_in = [first, second]
+        # events (created once, re-recorded): [q] the last reader of set q is done (recorded behind the replay / the priming
+        # pass); set q was written on the feed stream (the next replay of parity q waits for it)
+        cuda = self.device.type == "cuda"
+        self._ev_free = [torch.cuda.Event() for _ in (0, 1)] if cuda else None
+        self._ev_fed = [torch.cuda.Event() for _ in (0, 1)] if cuda else None
+        self._free_valid = [False, False]
+        self._fed_pending = [False, False]
+        self._run_stream = None
+        if self.device.type == "cuda" and self.feed_stream is None:
+            # lowest priority: the copies (164 MB per batch at B = 8, 576^2, most of it the 50 mask planes per image) have a whole
+            # step to finish in and must not take CU slots from the step's kernels
+            prio = 0
+            if os.environ.get("DISYOLO_FEED_LOW", "1") != "0":
+                try:
+                    prio = max(torch.cuda.Stream.priority_range())       # (largest number = lowest priority)
+                except Exception:
+                    prio = 0
+            self.feed_stream = torch.cuda.Stream(device=self.device, priority=prio)
+
+    PIPE_INPUTS = ("images", "clip_window", "labels", "true_boxes", "true_masks", "perm_det", "perm_gt")
+    feed_stream = None
+    _pipe_in = None
 
     def _use_parity(self, q: int) -> None:
         for i, bufs in self._xbuf.items():
             self.by_idx[i].act = bufs[q]
+        if self._pipe_in is not None:
+            for n, v in self._pipe_in[q].items():
+                setattr(self, n, v)
         self._build_descs()
 
-    def prime_pipeline(self) -> None:
-        """run the backbone once for the images currently set (fills parity 0); afterwards every
+    def prime_pipeline(self, images=None, clip_window=None) -> None:
+        """run the backbone once for ``images`` (default: the images last set) -- fills parity 0; afterwards every
         train_step consumes that result and computes the backbone of the NEXT images meanwhile"""
+        src = self.images
         self._use_parity(0)
+        if images is not None:
+            self._set_inputs(images, clip_window if clip_window is not None else self.clip_window)
+        elif src is not self.images:
+            self.images.copy_(src)
         self._forward_prefix(self._pipe_P, True)
         self._parity = 0
+        if self.device.type == "cuda":
+            for q in (0, 1):
+                # (both sets: whatever the caller's stream did before -- a validation sweep, an eager step -- is in front of it)
+                self._ev_free[q].record(torch.cuda.current_stream())
+                self._free_valid[q] = True
+                self._fed_pending[q] = False
+            self._run_stream = torch.cuda.current_stream()
+
+    def feed_context(self):
+        """``with net.feed_context(): batch = data.get(); net.set_batch(batch)`` -- in the pipelined step the batch of the NEXT
+        replay is produced and copied on a stream of its own, beside the replay that is running (two input sets, one per list);
+        ``train_step(None)`` then waits for that stream on the device.  Anywhere else: no-op, set_batch runs on the caller's
+        stream in front of the step, as before."""
+        if self._progs is not None and self._pipe_in is not None and self.feed_stream is not None:
+            return torch.cuda.stream(self.feed_stream)
+        return contextlib.nullcontext()
 
     def _build_dgrad_descs(self) -> None:
         """Data-gradient convs: forward kernel over dx with the flipped operand (wdg), pads
@@ -1000,7 +1052,7 @@ class YOLONet(object):
         the caller's stream does next."""
         return self._tail_open and self._overlap and self._prog is not None and self.by_idx[1].lock and not self.pair
 
-    def _set_inputs(self, images, clip_window, half: int = 0) -> None:
+    def _set_inputs(self, images, clip_window, half: int = 0, pipe_set: Optional[int] = None) -> None:
         if not self._inputs_free_of_tail():
             self.sync_lanes()
         images = torch.as_tensor(images)
@@ -1008,7 +1060,10 @@ class YOLONet(object):
             raise ValueError("images must be [%d,%d,%d,3] NHWC (batch size and image size are baked into the plan, "
                              "as in the reference: yolo/yolo3_net_pos.py:17)" % (self.B, self.S, self.S))
         cw = self.clip_window if not self.pair else self._in_sets[half]["clip_window"]
-        self.images[half * self.B:(half + 1) * self.B].copy_(images.to(self.device, F32, non_blocking=True))
+        img = self.images
+        if pipe_set is not None:
+            img, cw = self._pipe_in[pipe_set]["images"], self._pipe_in[pipe_set]["clip_window"]
+        img[half * self.B:(half + 1) * self.B].copy_(images.to(self.device, F32, non_blocking=True))
         cw.copy_(torch.as_tensor(clip_window).to(self.device, F32).reshape(self.B, 4))
 
     def forward(self, images, clip_window, det_thresh=cfg.OBJ_THRESHOLD, is_training: bool = False):
@@ -1108,9 +1163,41 @@ class YOLONet(object):
         even step, 1 = of the odd step after it; both are set before the even step runs."""
         if half and not self.pair:
             raise L.DisyoloError("set_batch(half=1) on a net built without backbone_pair")
+        if self._progs is not None and self._pipe_in is not None and not self.pair:
+            # the pipelined step: the inputs of the NEXT replay (list self._parity reads set self._parity)
+            q = self._parity
+            if self.feed_stream is not None and torch.cuda.current_stream() == self.feed_stream:
+                # feed_context(): beside the replay that is running -- the set's last reader was the replay before that one
+                if self._free_valid[q]:
+                    self.feed_stream.wait_event(self._ev_free[q])
+                elif self._run_stream is not None:
+                    self.feed_stream.wait_stream(self._run_stream)
+                self._set_batch_into(batch, self._pipe_in[q], q)
+                self._ev_fed[q].record(self.feed_stream)
+                self._fed_pending[q] = True
+            else:
+                # the caller's stream, in front of the step (ordered after everything that read either set): both sets, so that
+                # a batch set once and replayed (no feed per step) is what both lists read
+                for qq in (q, 1 - q):
+                    if self._fed_pending[qq]:          # (a feed-stream write of this set is still in flight)
+                        torch.cuda.current_stream().wait_event(self._ev_fed[qq])
+                        self._fed_pending[qq] = False
+                    self._set_batch_into(batch, self._pipe_in[qq], qq)
+                    if self._ev_free is not None:
+                        # (a later feed-stream write of this set must land after this one)
+                        self._ev_free[qq].record(torch.cuda.current_stream())
+                        self._free_valid[qq] = True
+            return
         self._set_inputs(batch["images"], batch["clip_window"], half)
-        dev = self.device
         tgt = self._in_sets[half] if self.pair else {n: getattr(self, n) for n in ("labels", "true_boxes", "true_masks", "perm_det", "perm_gt")}
+        self._set_labels_into(batch, tgt)
+
+    def _set_batch_into(self, batch: Dict, tgt: Dict, pipe_set: int) -> None:
+        self._set_inputs(batch["images"], batch["clip_window"], 0, pipe_set)
+        self._set_labels_into(batch, tgt)
+
+    def _set_labels_into(self, batch: Dict, tgt: Dict) -> None:
+        dev = self.device
         for t, key in zip(tgt["labels"], ("yolo3", "yolo2", "yolo1")):
             t.copy_(torch.as_tensor(batch[key]).to(dev, F32).reshape(t.shape))
         tgt["true_boxes"].copy_(torch.as_tensor(batch["true_boxes"]).to(dev, F32).reshape(tgt["true_boxes"].shape))
@@ -1822,6 +1909,7 @@ class YOLONet(object):
             def next_backbone():
                 # the next batch's backbone: lowest-priority lane (lane 2)
                 self._use_parity(1 - parity)
+                self.images = self._pipe_in[parity]["images"]     # (fed before THIS replay: labels of batch t, images of t + 1)
                 lane = int(os.environ.get("DISYOLO_PIPE_LANE", "2"))
                 L.lane_sync(0, lane)
                 L.set_lane(lane)
@@ -1863,6 +1951,28 @@ class YOLONet(object):
         return prog, marks, bwd_end
 
     def run_program(self) -> None:
+        if self._progs is not None and self._pipe_in is not None and self.device.type == "cuda":
+            q = self._parity
+            try:
+                self._run_pipelined_list(q)
+            finally:
+                self._ev_free[q].record(torch.cuda.current_stream())
+                self._free_valid[q] = True
+            return
+        self._run_program()
+
+    def _run_pipelined_list(self, q: int) -> None:
+        cur = torch.cuda.current_stream()
+        if cur == self.feed_stream:
+            raise L.DisyoloError("train_step inside feed_context(): the step must run on the caller's stream, only set_batch "
+                                 "(and what produces the batch) belongs on the feed stream")
+        if self._fed_pending[q]:
+            cur.wait_event(self._ev_fed[q])
+            self._fed_pending[q] = False
+        self._run_stream = cur
+        self._run_program()
+
+    def _run_program(self) -> None:
         if self._progs is not None:
             self._prog, self._prog_marks, self._bwd_end = self._progs[self._parity]
             self._parity ^= 1

@@ -174,8 +174,7 @@ class Solver(object):
         def prime():
             """(re)compute the backbone pass of the batch the next step trains on: at the start, and after anything that ran
             another forward pass through the net's buffers (the validation sweep)"""
-            net._set_inputs(ahead["images"], ahead["clip_window"])
-            net.prime_pipeline()
+            net.prime_pipeline(ahead["images"], ahead["clip_window"])
         if pipe and self.start_iter <= self.max_iter:
             ahead = self._next_feed()
             prime()
@@ -229,10 +228,14 @@ class Solver(object):
             elif pipe:
                 # the labels of this step's batch, the images of the next one (whose backbone pass this step runs beside its own
                 # heads / backward); one batch is read ahead -- the batches a step trains on are the reference's, in its order
-                nxt = self._feed()
-                feed = dict(ahead)
-                feed["images"] = nxt["images"]
-                ahead = nxt
+                # -- produced and copied on the net's feed stream, beside the step that is running (two input sets)
+                with net.feed_context():
+                    nxt = self._feed()
+                    feed = dict(ahead)
+                    feed["images"] = nxt["images"]
+                    ahead = nxt
+                    net.set_batch(feed)
+                feed = None
             else:
                 feed = self._next_feed()
             load_timer.toc()

@@ -436,6 +436,48 @@ def test_pipelined_backbone_step_equals_plain_step(dev):
         assert torch.equal(plain.params[name], piped.params[name]), name
 
 
+def test_pipelined_step_fed_on_the_feed_stream_equals_plain_step(dev):
+    """The pipelined step keeps TWO sets of per-batch inputs (list q reads set q): inside ``feed_context()`` the batch of the next
+    replay is copied on the net's feed stream while the current replay runs.  Eight steps without a host synchronisation in
+    between, device-resident batches (nothing serialises the copies by accident), against the plain step fed on the caller's
+    stream: the same losses and variables, bit for bit; and a feed on the caller's stream in between (both sets written) keeps
+    them so."""
+    B, S, N = 2, 64, 8
+    batches = [{k: (torch.as_tensor(v).to(dev) if v is not None else None) for k, v in O.synthetic_batch(B, S, seed=sd).items()}
+               for sd in (40, 41, 42, 43, 70, 71, 72, 73, 74)]
+    plain = make_net(dev, True, 1, B=B, S=S, seed=6)
+    piped = make_net(dev, True, 1, B=B, S=S, seed=6)
+    piped.load_state_dict(plain.state_dict())
+    plain.build_program(det_thresh=0.1)
+    piped.build_program(det_thresh=0.1, pipeline_backbone=True)
+    assert piped.feed_stream is not None
+    piped.prime_pipeline(batches[0]["images"], batches[0]["clip_window"])
+    for t in range(N):
+        plain.set_batch(batches[t])
+        plain.train_step(None, want_loss=False)
+        mixed = dict(batches[t])
+        mixed["images"] = batches[t + 1]["images"]        # labels of batch t, images of batch t+1
+        if t == 5:
+            piped.set_batch(mixed)                          # the caller's stream: both sets
+        else:
+            with piped.feed_context():
+                piped.set_batch(mixed)
+        piped.train_step(None, want_loss=False)
+    with pytest.raises(L.DisyoloError):
+        with piped.feed_context():
+            piped.train_step(None, want_loss=False)         # the step itself does not belong on the feed stream
+    torch.cuda.synchronize()
+    lp, lq = plain.step_losses(0, N), piped.step_losses(0, N)
+    assert np.isfinite(lp[:3]).all(), lp
+    # (bit patterns: a batch whose mask loss meets a zero-area RoI is NaN in the reference too, SURVEY.md B14 -- then in both)
+    assert lp.view(np.int32).tolist() == lq.view(np.int32).tolist(), (lp, lq)
+    same = lambda a, b: torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert same(plain.arena, piped.arena) and same(plain.adam_v, piped.adam_v)
+    for l in plain.layers:
+        if not l.lock and getattr(l, "mm", None) is not None:
+            assert same(l.mm, piped.by_idx[l.idx].mm), l.idx
+
+
 @pytest.mark.parametrize("recorded", [False, True])
 def test_backbone_pair_steps_match_plain_steps(dev, recorded):
     """Stage 1 with backbone_pair: the locked backbone runs once per two batches at batch size 2B, the trainable part steps
