@@ -666,7 +666,7 @@ class YOLONet(object):
         self._fed_pending = [False, False]
         self._run_stream = None
         if self.device.type == "cuda" and self.feed_stream is None:
-            # lowest priority: the copies (164 MB per batch at B = 8, 576^2, most of it the 50 mask planes per image) have a whole
+            # lowest priority: the copies (85 MB per batch at B = 8, 576^2: images 32 MB, the 20 mask planes per image 53 MB) have a whole
             # step to finish in and must not take CU slots from the step's kernels
             prio = 0
             if os.environ.get("DISYOLO_FEED_LOW", "1") != "0":
