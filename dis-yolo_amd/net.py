@@ -787,9 +787,13 @@ class YOLONet(object):
                 if plan[l.idx] is not None:
                     plan[l.idx]()
                 self._fp8_handover(l)
-                continue
-            self._forward_layer(l, is_training)
-            self._fp8_handover(l)
+            else:
+                self._forward_layer(l, is_training)
+                self._fp8_handover(l)
+            hook = getattr(self, "_fwd_hook", None)
+            if hook is not None and hook[0] == l.idx and L.CURRENT_LANE == 0:
+                self._fwd_hook = None
+                hook[1]()
         if self.use_side_lane:
             L.set_lane(0)
             L.lane_sync(1, 0)
@@ -1918,8 +1922,18 @@ class YOLONet(object):
                 self._use_parity(parity)
             if pipe_early:
                 next_backbone()      # (experiment: from the start of the step, beside the heads' forward pass as well)
+            started = [False]
+            fwd_after = int(os.environ.get("DISYOLO_PIPE_FWD_AFTER", "0")) if (parity is not None and not pipe_early) else 0
+            if fwd_after:
+                # (experiment: from behind forward layer DISYOLO_PIPE_FWD_AFTER of the trainable part, a main-lane layer)
+                def early_start():
+                    started[0] = True
+                    next_backbone()
+                self._fwd_hook = (fwd_after, early_start)
             self.compute_losses(det_thresh, first)
-            if parity is not None and not pipe_early:
+            self._fwd_hook = None
+            pipe_after = int(os.environ.get("DISYOLO_PIPE_AFTER", "0")) if (parity is not None and self.dp is None) else 0
+            if parity is not None and not pipe_early and pipe_after == 0 and not started[0]:
                 # ... started once the trunk's forward is done, so it fills what the backward pass leaves of the CUs
                 next_backbone()
             if self.dp is not None and not inl:
@@ -1933,6 +1947,17 @@ class YOLONet(object):
                     if bi is not None:
                         marks.append((prog.size(), bi))
                 self.backward(mark)
+            elif pipe_after > 0:
+                # (experiment: the backbone's launches issued behind the first DISYOLO_PIPE_AFTER layers of the backward pass)
+                done = [0]
+
+                def late_start(_l):
+                    done[0] += 1
+                    if done[0] == pipe_after:
+                        next_backbone()
+                self.backward(late_start, sweep=True)
+                if done[0] < pipe_after:
+                    next_backbone()
             else:
                 self.backward(sweep=True)
             bwd_end = prog.size()

@@ -1,5 +1,5 @@
 """Host time to enqueue one recorded training step vs the GPU time of the step (GPU box): is the step
-host-bound?   usage: python tools/host_enqueue.py [stage]"""
+host-bound?   usage: python tools/host_enqueue.py [stage] [plain]   (stage 1: the pipelined step unless "plain")"""
 import sys, time
 sys.path.insert(0, ".")
 import torch
@@ -11,7 +11,14 @@ B, S = 8, 576
 net = YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=stage, seed=0)
 net.set_batch(synthetic_batch(B, S, seed=1234))
 net.shuffle_seed = 1234
-net.build_program()
+import os
+cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "tune_train_B8_576_stage%d.json" % stage)
+if os.path.exists(cache):
+    net.autotune(cache=cache)
+pipe = stage == 1 and "plain" not in sys.argv
+net.build_program(pipeline_backbone=pipe, overlap_tail=not pipe)
+if pipe:
+    net.prime_pipeline()
 for _ in range(5):
     net.train_step(None, want_loss=False)
 torch.cuda.synchronize()
