@@ -712,7 +712,8 @@ class YOLONet(object):
         replay is produced and copied on a stream of its own, beside the replay that is running (two input sets, one per list);
         ``train_step(None)`` then waits for that stream on the device.  Anywhere else: no-op, set_batch runs on the caller's
         stream in front of the step, as before."""
-        if self._progs is not None and self._pipe_in is not None and self.feed_stream is not None:
+        if (self._progs is not None and self._pipe_in is not None and self.feed_stream is not None
+                and os.environ.get("DISYOLO_FEED_STREAM", "1") != "0"):
             return torch.cuda.stream(self.feed_stream)
         return contextlib.nullcontext()
 
@@ -1206,6 +1207,8 @@ class YOLONet(object):
             t.copy_(torch.as_tensor(batch[key]).to(dev, F32).reshape(t.shape))
         tgt["true_boxes"].copy_(torch.as_tensor(batch["true_boxes"]).to(dev, F32).reshape(tgt["true_boxes"].shape))
         tm = torch.as_tensor(batch["true_masks"])
+        if tm.dtype == torch.bool:
+            tm = tm.view(torch.uint8)         # (0 / 1 bytes either way: no conversion pass over the 53 MB of mask planes)
         tgt["true_masks"].copy_(tm.to(dev).to(torch.uint8).reshape(tgt["true_masks"].shape))
         if batch.get("perm_det") is not None:
             tgt["perm_det"].copy_(torch.as_tensor(batch["perm_det"]).to(dev, torch.int32).reshape(tgt["perm_det"].shape))

@@ -196,6 +196,27 @@ def test_defect_train_get_replayed_by_the_oracle(dev):
     assert torch.equal(a[0], b_[0]) and torch.equal(a[1], b_[1]) and np.array_equal(a[2], b_[2]) and np.array_equal(a[3], b_[3])
 
 
+def test_defect_train_record_cache_and_buffer_sets(dev):
+    """round 6: the per-record cache (image, instance masks, boxes on the GPU) changes nothing -- twelve batches with it against
+    twelve without (cache_bytes=0: everything recomputed per visit, as before), same seed, bit for bit; and a batch stays intact
+    through the next get() (two buffer sets), which is what a loop that reads one batch ahead holds on to."""
+    S, B = 96, 2
+    labels = _labels(np.random.RandomState(11), 5)
+    a = TD.defect_train(labels, batch_size=B, image_size=S, device=dev, rng=np.random.RandomState(3))
+    b = TD.defect_train(labels, batch_size=B, image_size=S, device=dev, rng=np.random.RandomState(3), cache_bytes=0)
+    prev = None
+    for _ in range(12):
+        ga, gb = a.get(), b.get()
+        assert not b._cache and len(a._cache) >= 1
+        assert torch.equal(ga[0], gb[0]) and torch.equal(ga[1], gb[1])
+        for x, y in zip(ga[2:], gb[2:]):
+            assert np.array_equal(x, y)
+        if prev is not None:
+            assert torch.equal(prev[0], prev[2]) and torch.equal(prev[1], prev[3])     # the batch before this one: untouched
+        prev = (ga[0], ga[1], ga[0].clone(), ga[1].clone())
+    assert a.epoch == b.epoch and a.epoch >= 4
+
+
 def test_defect_train_feeds_the_solver(dev, tmp_path):
     """end to end: polygons -> GPU pipeline -> Solver.train -> finite losses (the reference's main(), :237-248)"""
     from disyolo_amd.net import YOLONet
