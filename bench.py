@@ -319,6 +319,20 @@ def secondary_measurements(args, dev):
                                "conv_tiles": d["config"].get("conv_tiles"), "process": "child"}
     except Exception as e:   # a secondary line must never cost the headline
         out["train_stage2"] = {"error": repr(e)[:200]}
+    # the loop a user runs, end to end: polygon records -> the GPU data pipeline (train_data.defect_train) -> Solver.train
+    # (tools/solver_rate.py: host clock over the last 150 of 200 steps, device synchronised at the end)
+    if args.stage == 1 and args.dtype == "bf16" and args.batch == 8 and S == 576:
+        try:
+            r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "solver_rate.py"),
+                                "--steps", "200", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+            lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                raise RuntimeError("solver_rate exited with %d" % r.returncode)
+            out["train_stage1_solver_loop"] = dict(json.loads(lines[-1]), process="child",
+                                                   role="not a bench step: the reference's training loop (train_yolo3_mask.py:143-226) "
+                                                        "with its data loader, as a user runs it")
+        except Exception as e:
+            out["train_stage1_solver_loop"] = {"error": repr(e)[:200]}
     # the headline workload the way a training loop runs it: a new batch before every step (device-to-device set_batch
     # inside the timed region; the overlapped tail stays open across it -- nothing in the tail reads an input tensor)
     if args.stage == 1 and args.dtype == "bf16":
@@ -829,6 +843,8 @@ def main():
             fps = out["secondary"].get("train_stage1_feed_per_step", {})
             out["config"]["value_per_step_feed"] = fps.get("value")
             out["config"]["ms_per_step_per_step_feed"] = fps.get("ms_per_step")
+            # ... and the whole training loop with its data loader (Solver.train over the GPU data pipeline, tools/solver_rate.py)
+            out["config"]["value_solver_loop"] = out["secondary"].get("train_stage1_solver_loop", {}).get("value")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.stage, S)
         if kernels is not None:

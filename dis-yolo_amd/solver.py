@@ -133,6 +133,9 @@ class Solver(object):
                     f.write("{}: {}\n".format(key, cfg.__dict__[key]))
 
     def _feed(self):
+        on_device = getattr(self.data, "get_device", None)
+        if on_device is not None:
+            return on_device()       # (train_data.defect_train: every array already on the GPU, nothing waits for the device)
         images, true_masks, true_boxes, yolo_3, yolo_2, yolo_1, window = self.data.get()
         return {"images": images, "true_masks": true_masks, "true_boxes": true_boxes, "yolo3": yolo_3, "yolo2": yolo_2,
                 "yolo1": yolo_1, "clip_window": window}

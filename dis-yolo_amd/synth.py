@@ -12,11 +12,13 @@ import numpy as np
 from . import config as cfg
 
 
-def assign_targets(boxes_px, cls, S: int, num_class: int):
-    """utils/train_data.py:149-178: best-IoU anchor of the 9 (boxes centred at the origin),
-    cell = int(centre * grid / net); an occupied (cell, anchor) keeps its first box."""
+def assign_target_entries(boxes_px, cls, S: int, num_class: int):
+    """utils/train_data.py:149-178 as a sparse list: best-IoU anchor of the 9 (boxes centred at the origin),
+    cell = int(centre * grid / net); an occupied (cell, anchor) keeps its first box.  Returns, per scale (yolo3, yolo2,
+    yolo1), {(yi, xi, anchor): row float32 [5 + C]} in assignment order -- the non-zero rows of the dense target grids."""
     g1 = S // 32
-    yolos = [np.zeros((m * g1, m * g1, 3, 5 + num_class), np.float32) for m in (4, 2, 1)]
+    sizes = [4 * g1, 2 * g1, g1]
+    out = [dict() for _ in sizes]
     amax = np.asarray(cfg.ANCHORS, np.float32) / 2.0
     a_area = amax[:, 0] * amax[:, 1] * 4
     for b, c in zip(boxes_px, cls):
@@ -27,13 +29,26 @@ def assign_targets(boxes_px, cls, S: int, num_class: int):
         if iou.max() <= 0:
             continue
         idx = int(np.argmax(iou))
-        y = yolos[idx // 3]
-        xi, yi = int(b[0] * y.shape[1] / S), int(b[1] * y.shape[0] / S)
-        if y[yi, xi, idx % 3, 4] == 1:
+        g = sizes[idx // 3]
+        xi, yi = int(b[0] * g / S), int(b[1] * g / S)
+        key = (yi, xi, idx % 3)
+        if key in out[idx // 3]:
             continue
-        y[yi, xi, idx % 3, 0:4] = b[:4]
-        y[yi, xi, idx % 3, 4] = 1
-        y[yi, xi, idx % 3, 5 + int(c)] = 1.0
+        row = np.zeros(5 + num_class, np.float32)
+        row[0:4] = b[:4]
+        row[4] = 1
+        row[5 + int(c)] = 1.0
+        out[idx // 3][key] = row
+    return out
+
+
+def assign_targets(boxes_px, cls, S: int, num_class: int):
+    """the dense grids of utils/train_data.py:149-178: [g, g, 3, 5 + C] per scale (yolo3, yolo2, yolo1)"""
+    g1 = S // 32
+    yolos = [np.zeros((m * g1, m * g1, 3, 5 + num_class), np.float32) for m in (4, 2, 1)]
+    for y, ent in zip(yolos, assign_target_entries(boxes_px, cls, S, num_class)):
+        for (yi, xi, a), row in ent.items():
+            y[yi, xi, a] = row
     return yolos
 
 

@@ -17,8 +17,9 @@ NEXT ``get()`` and is overwritten by the one after it (a training loop that read
 Round 6: what does not depend on the random draws is computed ONCE per record and kept on the GPU -- the decoded image, the
 rasterised instance masks, their boxes (``load_mask`` / ``load_box`` of the reference run again on every visit of an image and return
 the same arrays every time).  A 1000 x 1000 image with three instances is 6 MB; ``cache_bytes`` (default 16 GiB of the 288) bounds
-it, records beyond the budget are recomputed per visit as before.  With it ``get()`` has no host synchronisation left: 7.5 -> 1.9 ms
-per batch of 8 at 576^2 (``tools/solver_rate.py``).
+it, records beyond the budget are recomputed per visit as before.  With it ``get()`` has no host synchronisation left; with the
+target grids kept sparse on the host (a dozen rows in 5 MB of zeros) and uploaded from pinned staging: 7.5 -> 1.5 ms per batch of 8 at 576^2, and ``Solver.train`` end to end 630 -> 2120 images/s
+(``tools/solver_rate.py``: the step's own rate).
 """
 from __future__ import annotations
 
@@ -31,7 +32,7 @@ import torch
 
 from . import config as cfg
 from . import lib as L
-from .synth import assign_targets
+from .synth import assign_target_entries
 
 
 def rasterize_instance(polys: Sequence[Dict], image_h: int, image_w: int, device, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -89,6 +90,20 @@ class defect_train(object):
                        torch.zeros(B, G, S, S, dtype=torch.uint8, device=dev)) for _ in range(2)]
         self._turn = 0
         self.images, self.true_masks = self._sets[0]
+        # the small host-built arrays (true_boxes, the three target grids, the clip windows): per set a staging copy on the host
+        # (pinned where there is a GPU: its upload is asynchronous), the device copy get_device() hands out, the cells the
+        # last fill of the set wrote (only those are cleared again: the grids are 5 MB of zeros around a dozen rows) and an
+        # event behind the set's last upload
+        cuda = dev.type == "cuda"
+        g1 = self.base_grid
+        shapes = [(B, 1, 1, 1, G, 5)] + [(B, g, g, 3, 5 + self.num_class) for g in (4 * g1, 2 * g1, g1)] + [(B, 4)]
+        self._host = [[torch.zeros(sh, dtype=torch.float32, pin_memory=cuda) for sh in shapes] for _ in range(2)]
+        self._dev = [[torch.zeros(sh, dtype=torch.float32, device=dev) for sh in shapes] for _ in range(2)]
+        self._written = [[], []]
+        self._uploaded = [None, None]
+        for st in self._host:
+            st[4][:, 2:] = 1.0                                 # window = (0, 0, 1, 1), :46-47
+        self._last = None
         self._frame = [torch.zeros(S, S, 3, dtype=torch.uint8, device=dev) for _ in range(2)]
         self.last_decisions: List[Dict] = []                   # the random draws of the last get(), for tests / logging
         # per-record static part (image on the GPU, instance masks, boxes, classes), keyed by the record object
@@ -126,15 +141,35 @@ class defect_train(object):
         return entry
 
     def get(self):
+        """the reference's tuple: (images, true_masks) on the GPU, (true_boxes, yolo_3, yolo_2, yolo_1, window) numpy"""
+        self._fill()
+        h = self._host[self._last]
+        return (self.images, self.true_masks.view(torch.bool), h[0].numpy(), h[1].numpy(), h[2].numpy(), h[3].numpy(), h[4].numpy())
+
+    def get_device(self) -> Dict[str, torch.Tensor]:
+        """the same batch as ``YOLONet.set_batch``'s dict with EVERY array on the GPU (the small ones uploaded from pinned
+        staging on the current stream, asynchronously): a training loop fed this way never waits for the device
+        (``Solver.train`` uses it when the data object has it)"""
+        self._fill()
+        d = self._dev[self._last]
+        return {"images": self.images, "true_masks": self.true_masks.view(torch.bool), "true_boxes": d[0], "yolo3": d[1],
+                "yolo2": d[2], "yolo1": d[3], "clip_window": d[4]}
+
+    def _fill(self) -> None:
         B, S, G, rng = self.batch_size, self.image_size, self.max_box_per_image, self.rng
         dev = self.device
-        self.images, self.true_masks = self._sets[self._turn]
+        turn = self._turn
         self._turn ^= 1
-        window = np.zeros((B, 4), np.float32)
-        window[:, :] = [0.0, 0.0, 1.0, 1.0]
-        true_boxes = np.zeros((B, 1, 1, 1, G, 5), np.float32)
-        g1 = self.base_grid
-        ys = [np.zeros((B, g, g, 3, 5 + self.num_class), np.float32) for g in (4 * g1, 2 * g1, g1)]   # yolo3, yolo2, yolo1
+        self._last = turn
+        self.images, self.true_masks = self._sets[turn]
+        if self._uploaded[turn] is not None:
+            self._uploaded[turn].synchronize()                 # (the upload of two batches ago: long done)
+        host = self._host[turn]
+        true_boxes, ys = host[0].numpy(), [host[1].numpy(), host[2].numpy(), host[3].numpy()]   # yolo3, yolo2, yolo1
+        true_boxes[...] = 0.0
+        for k, b, yi, xi, a in self._written[turn]:
+            ys[k][b, yi, xi, a] = 0.0
+        written = self._written[turn] = []
         self.true_masks.zero_()
         self.last_decisions = []
         for count in range(B):
@@ -179,23 +214,26 @@ class defect_train(object):
                 x2 = max(min(float(x2) * sx + dx, net_w - 1), 0)
                 y2 = max(min(float(y2) * sy + dy, net_h - 1), 0)
                 bx[j] = [(x2 + x1) / 2.0, (y2 + y1) / 2.0, x2 - x1, y2 - y1]
-            grids = assign_targets(bx, cls, S, self.num_class)                               # pixel units, like the reference here
+            # (the non-zero rows of the three grids, {(yi, xi, anchor): row}: pixel units, like the reference here)
+            grids = assign_target_entries(bx, cls, S, self.num_class)
             # ---- step 2: flip (:187-226) -- the grids are mirrored and the stored centres reflected
             flip = 1
             if self.flipped:
                 flip = int(rng.randint(low=1, high=4))
             if flip == 2:
                 bx[:, 0] = net_w - 1 - bx[:, 0]
-                grids = [g[:, ::-1].copy() for g in grids]
-                for g in grids:
-                    obj = g[..., 4] == 1
-                    g[..., 0][obj] = net_w - 1 - g[..., 0][obj]
+                for k, ent in enumerate(grids):
+                    gsz = ys[k].shape[1]
+                    for row in ent.values():
+                        row[0] = np.float32(net_w - 1) - row[0]
+                    grids[k] = {(yi, gsz - 1 - xi, a): row for (yi, xi, a), row in ent.items()}
             elif flip == 3:
                 bx[:, 1] = net_h - 1 - bx[:, 1]
-                grids = [g[::-1].copy() for g in grids]
-                for g in grids:
-                    obj = g[..., 4] == 1
-                    g[..., 1][obj] = net_h - 1 - g[..., 1][obj]
+                for k, ent in enumerate(grids):
+                    gsz = ys[k].shape[1]
+                    for row in ent.values():
+                        row[1] = np.float32(net_h - 1) - row[1]
+                    grids[k] = {(gsz - 1 - yi, xi, a): row for (yi, xi, a), row in ent.items()}
             # ---- step 3: blur / noise / light (:228-241)
             bnl = 1
             if self.blur_noise_light:
@@ -231,10 +269,11 @@ class defect_train(object):
             # ---- normalise (:250-257)
             true_boxes[count, 0, 0, 0, :len(bx), :4] = bx / S
             true_boxes[count, 0, 0, 0, :len(bx), 4] = cls
-            for dst, g in zip(ys, grids):
-                g = g.copy()
-                g[..., 0:4] = g[..., 0:4] / S
-                dst[count] = g
+            for k, ent in enumerate(grids):
+                for (yi, xi, a), row in ent.items():
+                    row[0:4] = row[0:4] / np.float32(S)
+                    ys[k][count, yi, xi, a] = row
+                    written.append((k, count, yi, xi, a))
             self.last_decisions.append(dec)
             self.cursor += 1
             if self.cursor >= len(self.gt_labels):                                          # :266-271
@@ -242,4 +281,10 @@ class defect_train(object):
                 self.random_labels = copy.copy(self.gt_labels)
                 self.cursor = 0
                 self.epoch += 1
-        return (self.images, self.true_masks.view(torch.bool), true_boxes, ys[0], ys[1], ys[2], window)
+        if dev.type == "cuda":
+            for h, d in zip(host, self._dev[turn]):
+                d.copy_(h, non_blocking=True)
+            self._uploaded[turn] = torch.cuda.current_stream().record_event()
+        else:
+            for h, d in zip(host, self._dev[turn]):
+                d.copy_(h)

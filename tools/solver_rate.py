@@ -26,6 +26,7 @@ ap.add_argument("--steps", type=int, default=300)
 ap.add_argument("--pipeline", default="auto")
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--size", type=int, default=576)
+ap.add_argument("--json", action="store_true", help="one JSON line instead of the sentence (bench.py's secondary)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 labels = synthetic_labels(np.random.RandomState(0), 64)
@@ -42,6 +43,16 @@ def get():
 
 
 data.get = get
+if hasattr(data, "get_device") and os.environ.get("SOLVER_RATE_HOST_LABELS") != "1":
+    inner_dev = data.get_device
+
+    def get_device():
+        stamps.append(time.perf_counter())
+        return inner_dev()
+    data.get_device = get_device
+    inner = inner_dev
+else:
+    data.get_device = None
 # the data pipeline alone first (its own GPU time per batch)
 for _ in range(5):
     inner()
@@ -62,6 +73,13 @@ with tempfile.TemporaryDirectory() as out:
 skip = 50
 n = len(stamps) - skip
 dt = (t_end - stamps[skip]) / n
+if args.json:
+    import json
+    print(json.dumps({"workload": "Solver.train over train_data.defect_train (GPU data pipeline), B%d %dx%d, stage 1" % (args.batch, args.size, args.size),
+                      "value": round(args.batch / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3), "steps": n,
+                      "data_pipeline_alone_ms_per_batch": round(t_data * 1e3, 3), "finite_losses": int(np.isfinite(hist).sum()),
+                      "records": len(labels)}))
+    sys.exit(0)
 print("data pipeline alone %.3f ms per batch; Solver.train: %d steps, %.3f ms per step = %.1f images/s (pipeline %s, feed stream %s); "
       "finite losses %d of %d" % (t_data * 1e3, n, dt * 1e3, args.batch / dt, args.pipeline, os.environ.get("DISYOLO_FEED_STREAM", "1"),
                                   int(np.isfinite(hist).sum()), len(hist)))
