@@ -5,8 +5,10 @@ the copy to the device is part of the step.  At B = 8, 576x576 that is 90 MB (im
 targets and boxes 5 MB) = 1.9 ms over PCIe against a 4.5 ms step when done synchronously.  ``HostFeeder`` keeps two
 device staging sets: while step t runs, batch t+1 is copied from pinned host memory on a copy stream; at the start
 of step t+1 the compute stream waits for that copy's event and moves the staging set into the network's input
-buffers device-to-device (40 us).  Measured (tools/feed_rate.py, pinned host batches): stage 1 1828 img/s with resident inputs, 1294 with a
-synchronous feed, 1778 with this one; stage 2 772 / 649 / 762.
+buffers device-to-device (40 us).  Measured (tools/feed_rate.py, pinned host batches, round 2): stage 1 1828 img/s with resident inputs, 1294 with a
+synchronous feed, 1778 with this one; stage 2 772 / 649 / 762.  Round 6: on a net whose step is the pipelined one the feeder hands
+over the labels of batch t with the images of batch t + 1 and moves them on the net's feed stream (``YOLONet.feed_context``);
+2074 img/s against 2180 resident and 1438 synchronous.
 """
 from __future__ import annotations
 
@@ -28,6 +30,7 @@ class HostFeeder:
         self.consumed = [torch.cuda.Event(), torch.cuda.Event()]
         for e in self.consumed:
             e.record()
+        self._primed = False   # (pipelined nets: the first batch's backbone pass has been run)
         self.head = 0          # staging set the next submit() fills
         self.pending = []      # sets filled and not yet consumed, oldest first
 
@@ -62,10 +65,14 @@ class HostFeeder:
         host = self._as_host(k, batch)
         if self.staging[k] is None:
             self.staging[k] = {key: torch.empty(v.shape, dtype=v.dtype, device=self.dev) for key, v in host.items()}
-        with torch.cuda.stream(self.copy_stream):
+        # (a pipelined net: its own feed stream carries the uploads too -- one probed stream, never parked on another's event)
+        cs = self.copy_stream
+        if getattr(self.net, "_pipe_in", None) is not None and getattr(self.net, "feed_stream", None) is not None:
+            cs = self.net.feed_stream
+        with torch.cuda.stream(cs):
             for key, v in host.items():
                 self.staging[k][key].copy_(v, non_blocking=True)
-            self.ready[k].record(self.copy_stream)
+            self.ready[k].record(cs)
         self.pending.append(k)
         self.head = 1 - k
 
@@ -74,9 +81,29 @@ class HostFeeder:
         if not self.pending:
             raise RuntimeError("HostFeeder: no batch submitted")
         k = self.pending.pop(0)
-        torch.cuda.current_stream().wait_event(self.ready[k])
-        self.net.set_batch(self.staging[k])            # device-to-device on the compute stream
-        self.consumed[k].record()
+        net = self.net
+        if getattr(net, "_progs", None) is not None and getattr(net, "_pipe_in", None) is not None:
+            # the pipelined step (YOLONet.build_program(pipeline_backbone=True)): labels of THIS batch, images of the NEXT
+            # submitted one (whose backbone pass this step runs); the move into the net's input set happens on the net's
+            # feed stream, beside the step that is still running.  The last step of a loop has no next batch: its own images
+            # go in again (that backbone pass is not used by anybody).
+            k1 = self.pending[0] if self.pending else k
+            if not self._primed:
+                torch.cuda.current_stream().wait_event(self.ready[k])
+                net.prime_pipeline(self.staging[k]["images"], self.staging[k]["clip_window"])
+                self._primed = True
+            mixed = dict(self.staging[k])
+            mixed["images"] = self.staging[k1]["images"]
+            with net.feed_context():
+                fs = torch.cuda.current_stream()
+                fs.wait_event(self.ready[k])
+                fs.wait_event(self.ready[k1])
+                net.set_batch(mixed)
+                self.consumed[k].record(fs)
+        else:
+            torch.cuda.current_stream().wait_event(self.ready[k])
+            net.set_batch(self.staging[k])             # device-to-device on the compute stream
+            self.consumed[k].record()
         if det_thresh is None:
             return self.net.train_step(None, want_loss=want_loss)
         return self.net.train_step(None, det_thresh=det_thresh, want_loss=want_loss)

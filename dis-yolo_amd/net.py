@@ -665,16 +665,24 @@ class YOLONet(object):
         self._free_valid = [False, False]
         self._fed_pending = [False, False]
         self._run_stream = None
-        if self.device.type == "cuda" and self.feed_stream is None:
-            # lowest priority: the copies (85 MB per batch at B = 8, 576^2: images 32 MB, the 20 mask planes per image 53 MB) have a whole
-            # step to finish in and must not take CU slots from the step's kernels
+        self.feed_stream = None            # (chosen once the lists exist: _pick_feed_stream)
+
+    def _pick_feed_stream(self) -> None:
+        """the stream ``feed_context()`` puts the next batch on.  Single-GPU: lane 3 of the executor's pool (the gradient exchange's
+        lane, idle without data parallelism) -- a stream the pool PROBED to run beside the main lane and not to slow it while
+        parked on an event (csrc/runtime.hip pool_lane; profiles/r05_hw_queues.txt).  An arbitrary new stream can be the other
+        kind of neighbour: the host feeder's copies parked its stream on a 2-ms upload and the step beside it took 7.1 ms instead
+        of 3.6 (tools/feed_rate.py).  Data parallel: lane 3 is taken, a plain lowest-priority stream has to do."""
+        if self.device.type != "cuda":
+            return
+        if self.dp is None and os.environ.get("DISYOLO_FEED_LANE", "1") != "0":
+            self.feed_stream = self._progs[0][0].lane_stream(L.COMM_LANE, self.device)
+            return
+        try:
+            prio = max(torch.cuda.Stream.priority_range())       # (largest number = lowest priority)
+        except Exception:
             prio = 0
-            if os.environ.get("DISYOLO_FEED_LOW", "1") != "0":
-                try:
-                    prio = max(torch.cuda.Stream.priority_range())       # (largest number = lowest priority)
-                except Exception:
-                    prio = 0
-            self.feed_stream = torch.cuda.Stream(device=self.device, priority=prio)
+        self.feed_stream = torch.cuda.Stream(device=self.device, priority=prio)
 
     PIPE_INPUTS = ("images", "clip_window", "labels", "true_boxes", "true_masks", "perm_det", "perm_gt")
     feed_stream = None
@@ -1850,6 +1858,7 @@ class YOLONet(object):
             for q in (0, 1):
                 prog, marks, bwd_end = self._record_step(det_thresh, q)
                 self._progs.append((prog, marks, bwd_end))
+            self._pick_feed_stream()
             self._use_parity(0)
             self.ws.frozen = True
             self.ws_aux.frozen = True

@@ -183,6 +183,38 @@ def test_solver_train_loop_cadence_checkpoints_and_schedule(dev, tmp_path):
     assert not torch.equal(fresh.params["yolo/convolutional80/weights"], nets[0].params["yolo/convolutional80/weights"])
 
 
+def test_host_feeder_on_the_pipelined_step_trains_like_set_batch(dev):
+    """the same on a net whose recorded step is the pipelined one: the feeder mixes labels of batch t with the images of batch
+    t + 1 itself, primes the first backbone pass and moves the batch on the net's feed stream -- five host batches, the plain
+    net's weights bit for bit"""
+    from disyolo_amd.feed import HostFeeder
+    B, S, N = 2, 64, 5
+    nets = [YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=1, seed=4) for _ in range(2)]
+    for n in nets:
+        seeded_heads(n, 8)
+        n.shuffle_seed = 3
+    batches = [O.synthetic_batch(B, S, seed=300 + t) for t in range(N)]
+    plain, fed = nets
+    plain.set_batch(batches[0])
+    plain.build_program(det_thresh=0.1)
+    fed.set_batch(batches[0])
+    fed.build_program(det_thresh=0.1, pipeline_backbone=True)
+    for b in batches:
+        plain.set_batch(b)
+        plain.train_step(None, want_loss=False)
+    feeder = HostFeeder(fed)
+    feeder.submit(batches[0])
+    for t in range(N):
+        if t + 1 < N:
+            feeder.submit(batches[t + 1])
+        feeder.step(want_loss=False)
+    torch.cuda.synchronize()
+    lp, lq = plain.step_losses(0, N), fed.step_losses(0, N)
+    assert lp.view(np.int32).tolist() == lq.view(np.int32).tolist(), (lp, lq)
+    same = lambda a, b: torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert same(plain.arena, fed.arena) and same(plain.adam_v, fed.adam_v)
+
+
 def test_host_feeder_trains_like_set_batch(dev):
     """feed.HostFeeder (pinned host batch -> copy stream -> staging -> input buffers, one batch ahead) changes when
     the inputs arrive, not what is computed: three steps on three different host batches leave the same weights,

@@ -2,7 +2,7 @@
 uint8, targets, boxes: 90 MB per step at B=8, 576x576 -- through a copy stream into a device staging set (double
 buffered), then device-to-device into the network's input buffers at the start of the step.  Prints the rate with
 resident inputs (what bench.py reports), with a synchronous feed, and with the overlapped feed.
-usage: python tools/feed_rate.py [stage]"""
+usage: python tools/feed_rate.py [stage] [plain]"""
 import sys, time
 sys.path.insert(0, ".")
 import torch, bench
@@ -14,8 +14,13 @@ net = YOLONet(training=True, device=dev, image_size=S, batch_size=B, stage=stage
 batch = synthetic_batch(B, S, seed=1234)
 net.set_batch(batch)
 net.shuffle_seed = 1234
-net.autotune()
-net.build_program()
+import os
+cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "tune_train_B8_576_stage%d.json" % stage)
+net.autotune(cache=cache if os.path.exists(cache) else None)
+pipe = stage == 1 and "plain" not in sys.argv       # (round 6: the step bench.py and Solver run in stage 1 is the pipelined one)
+net.build_program(pipeline_backbone=pipe, overlap_tail=not pipe)
+if pipe:
+    net.prime_pipeline()
 keys = ("images", "clip_window", "true_boxes", "true_masks", "yolo1", "yolo2", "yolo3")
 host = {k: torch.as_tensor(batch[k]).contiguous() for k in keys}
 host["true_masks"] = host["true_masks"].to(torch.uint8)
