@@ -778,6 +778,7 @@ class YOLONet(object):
 
     def _forward_layers(self, is_training: bool, first: int = 1) -> None:
         plan = self._fusion_plan(is_training, first, 82)
+        xwaits = []
         for l in self.layers:
             if l.idx < first:
                 continue
@@ -788,10 +789,16 @@ class YOLONet(object):
                 elif l.idx in (60, 68, 76):
                     L.set_lane(0)
             if self._overlap_rec:
-                if l.idx in self._xstep_waits and (l.idx not in plan or plan[l.idx] is not None):
-                    L.lane_wait_slot(self._xstep_waits[l.idx], 0)     # the previous replay's last reader of this layer's output
+                # cross-replay waits are emitted in front of the first launch that EXECUTES at or after their layer (a layer
+                # fused away into a later launch -- plan entry None -- carries its wait forward, it is never dropped)
+                if l.idx in self._xstep_waits:
+                    xwaits.append(self._xstep_waits[l.idx])         # the previous replay's last reader of this layer's output
                 if l.idx == self._xstep_first_trainable and not self._xstep_all_merged:
-                    L.lane_wait_slot(self.SLOT_ALL, 0)                # the previous replay's optimizer + re-pack
+                    xwaits.append(self.SLOT_ALL)                     # the previous replay's optimizer + re-pack
+                if xwaits and (l.idx not in plan or plan[l.idx] is not None):
+                    for slot in xwaits:
+                        L.lane_wait_slot(slot, 0)
+                    xwaits.clear()
             if l.idx in plan:
                 if plan[l.idx] is not None:
                     plan[l.idx]()
@@ -1531,9 +1538,10 @@ class YOLONet(object):
             # latency-bound BN kernels of the following layers
             # ... except for the last few layers of the pass: nothing is left on the main lane to
             # overlap with, the step would only wait for the side lane's backlog to drain
-            # (with data parallelism every weight gradient stays on the side lane: the bucket all-reduce is
-            # ordered after that lane only, and both lanes would share ws_aux otherwise)
-            tail = 0 if self.dp is not None else self.tail_on_main
+            # (data parallelism with a CUT list: every weight gradient stays on the side lane -- the bucket all-reduce is ordered
+            # after that lane only.  With the exchange in the list the slices whose last weight gradient ran on the main lane are
+            # exchanged and swept in optimizer_step, whose exchange lane waits for the main lane, which has joined the side lane)
+            tail = self.tail_on_main if (self.dp is None or (inl and os.environ.get("DISYOLO_DP_TAIL_MAIN", "1") != "0")) else 0
             side = self.use_side_lane and (pos < len(order) - tail) and os.environ.get("DISYOLO_EXP_SKIP_WGRAD") != "2"
             # enqueue order = host order: the data-gradient convs (critical chain, main lane) are issued before the
             # weight gradient, which only needs dx.  The edge to the side lane is an event RECORDED ON THE MAIN LANE, and a
@@ -1848,7 +1856,7 @@ class YOLONet(object):
         if pipeline_backbone:
             if graph:
                 raise L.DisyoloError("pipeline_backbone uses the list executor, not a hipGraph")
-            if "DISYOLO_TAIL_MAIN" not in os.environ and self.dp is None:
+            if "DISYOLO_TAIL_MAIN" not in os.environ and (self.dp is None or self.dp.inlist):
                 # the pipelined step joins its lanes at the end of every replay: the weight gradients of the LAST two layers of
                 # the backward pass stay on the main lane, which would only wait for them (tail 0 / 1 / 2 / 3 / 4 / 6 / 8 layers:
                 # 3.82 / 3.80 / 3.76 / 3.76 / 3.81 / 3.85 / 3.94 ms per step, profiles/r06_backbone_pipeline.txt)
