@@ -272,4 +272,216 @@ done
 timeout 1500 python tools/instep_sweep.py --stage 1 --out gpurun_out/r06_sweep1p.json --budget 1000 > $O/r06_sweep1p.txt 2>&1; grep -E "^base|^final" $O/r06_sweep1p.txt
 }
 
+call36() {
+timeout 900 python tools/instep_sweep.py --stage 1 --table profiles/tune_train_B8_576_stage1.json --compare profiles/tune_train_B8_576_stage1_r06p.json --rounds 6 > $O/r06_sweep1p_compare.txt 2>&1; tail -3 $O/r06_sweep1p_compare.txt | cut -c1-300
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*'[:70], '|', d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'), d['config'].get('loss_last'))
+"; }
+C="--no-secondary --no-cpu-baseline --no-box --no-kernel-events"
+for r in 1 2; do
+for m in 8 12 16 24 32; do b DISYOLO_OPT_CHUNK_M=$m timeout 300 python bench.py $C; done
+b DISYOLO_OPT_CHUNK_M=16 timeout 300 python bench.py $C --tune-cache profiles/tune_train_B8_576_stage1_r06p.json
+done
+}
+
+call37() {
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*'[:60], '|', d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'), d['config'].get('loss_last'))
+"; }
+C="--no-secondary --no-cpu-baseline --no-box --no-kernel-events"
+for r in 1 2; do
+b A=1 timeout 300 python bench.py $C
+b DISYOLO_OPT_OVERLAP=1 timeout 300 python bench.py $C
+b DISYOLO_BN_INKERNEL=0 timeout 300 python bench.py $C
+b DISYOLO_WGRAD_GROUP=1 timeout 300 python bench.py $C
+b DISYOLO_WGRAD_GROUP=2 timeout 300 python bench.py $C
+b DISYOLO_WGRAD_GROUP=4 timeout 300 python bench.py $C
+b DISYOLO_WGRAD_GROUP=6 timeout 300 python bench.py $C
+b DISYOLO_LANE1_LOW=0 timeout 300 python bench.py $C
+b DISYOLO_TAIL_MAIN=3 timeout 300 python bench.py $C
+b DISYOLO_TAIL_MAIN=1 timeout 300 python bench.py $C
+done
+}
+
+call38() {
+timeout 900 python -m pytest tests/test_gpu_conv.py -x -q -k "batchnorm_backward or refuse_the_flag or partials" > $O/r06_t38a.txt 2>&1; echo "conv rc=$?"; tail -5 $O/r06_t38a.txt
+timeout 1500 python -m pytest tests/test_gpu_net.py tests/test_gpu_bn_inkernel.py -x -q > $O/r06_t38b.txt 2>&1; echo "net rc=$?"; tail -5 $O/r06_t38b.txt
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*'[:60], '|', d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'), d['config'].get('loss_last'))
+"; }
+C="--no-secondary --no-cpu-baseline --no-box --no-kernel-events"
+for r in 1 2 3; do
+b DISYOLO_BN_BWD_STATS_GEMM=1 timeout 300 python bench.py $C
+b DISYOLO_BN_BWD_STATS_GEMM=0 timeout 300 python bench.py $C
+done
+for r in 1 2; do
+b DISYOLO_BN_BWD_STATS_GEMM=1 timeout 300 python bench.py $C --stage 2 --steps 10 --repeats 5
+b DISYOLO_BN_BWD_STATS_GEMM=0 timeout 300 python bench.py $C --stage 2 --steps 10 --repeats 5
+done
+python - <<'PY'
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+import disyolo_amd
+from disyolo_amd.net import YOLONet
+from disyolo_amd.synth import synthetic_batch
+for stage in (1, 2):
+    net = YOLONet(training=True, device=torch.device("cuda:0"), image_size=576, batch_size=8, stage=stage, seed=0)
+    net.set_batch(synthetic_batch(8, 576, seed=1))
+    net.autotune(cache="profiles/tune_train_B8_576_stage%d.json" % stage)
+    net.train_step(); torch.cuda.synchronize()
+    tr = [l for l in net.layers if not l.lock and l.kind != "lin"]
+    print("stage", stage, "trainable BN layers", len(tr), "with partial rows", sum(1 for l in tr if l.bwd_part_rows), "without:", [l.idx for l in tr if not l.bwd_part_rows])
+PY
+}
+
+call40() {
+timeout 1500 python -m pytest tests/test_gpu_net.py tests/test_gpu_configs.py tests/test_gpu_drivers.py tests/test_gpu_conv.py -x -q > $O/r06_t40.txt 2>&1; echo "tests rc=$?"; tail -5 $O/r06_t40.txt
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*'[:80], '|', d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'), d['config'].get('loss_last'))
+"; }
+C="--no-secondary --no-cpu-baseline --no-box --no-kernel-events"
+for r in 1 2 3; do
+b A=1 timeout 300 python bench.py $C
+b A=1 timeout 300 python bench.py $C --feed per-step
+done
+}
+
+call41() {
+timeout 1500 python -m pytest tests/test_gpu_net.py tests/test_gpu_configs.py tests/test_gpu_drivers.py -x -q > $O/r06_t41.txt 2>&1; echo "tests rc=$?"; tail -5 $O/r06_t41.txt
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*'[:80], '|', d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'), d['config'].get('loss_last'))
+"; }
+C="--no-secondary --no-cpu-baseline --no-box --no-kernel-events"
+for r in 1 2 3; do
+b A=1 timeout 300 python bench.py $C
+b DISYOLO_FEED_LOW=1 timeout 300 python bench.py $C --feed per-step
+b DISYOLO_FEED_LOW=0 timeout 300 python bench.py $C --feed per-step
+done
+}
+
+call42() {
+timeout 2400 python -m pytest tests/test_gpu_net.py tests/test_gpu_configs.py tests/test_gpu_drivers.py tests/test_gpu_train_data.py tests/test_gpu_dp2.py -x -q > $O/r06_t42.txt 2>&1; echo "tests rc=$?"; tail -5 $O/r06_t42.txt
+timeout 600 python examples/train_synthetic.py > $O/r06_example.txt 2>&1; echo "example rc=$?"; tail -5 $O/r06_example.txt
+}
+
+call45() {
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*'[:60], '|', d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'), d['config'].get('loss_last'))
+"; }
+C="--no-secondary --no-cpu-baseline --no-box --no-kernel-events"
+for r in 1 2; do
+for n in 0 3 6 9 12 18; do b DISYOLO_PIPE_AFTER=$n timeout 300 python bench.py $C; done
+done
+}
+
+call46() {
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*'[:60], '|', d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'), d['config'].get('loss_last'))
+"; }
+C="--no-secondary --no-cpu-baseline --no-box --no-kernel-events"
+for r in 1 2; do
+for n in 0 55 57 61 65 69 73 77 81; do b DISYOLO_PIPE_FWD_AFTER=$n timeout 300 python bench.py $C; done
+done
+}
+
+call47() {
+for r in 1 2; do
+timeout 600 python tools/solver_rate.py 2>&1 | tail -1
+DISYOLO_FEED_STREAM=0 timeout 600 python tools/solver_rate.py 2>&1 | tail -1
+timeout 600 python tools/solver_rate.py --pipeline off 2>&1 | tail -1
+done
+}
+
+call48() {
+timeout 900 python -m pytest tests/test_gpu_train_data.py tests/test_gpu_drivers.py -x -q > $O/r06_t48.txt 2>&1; echo "tests rc=$?"; tail -4 $O/r06_t48.txt
+for r in 1 2; do
+timeout 600 python tools/solver_rate.py 2>&1 | tail -1
+DISYOLO_FEED_STREAM=0 timeout 600 python tools/solver_rate.py 2>&1 | tail -1
+done
+timeout 600 python tools/solver_rate.py --pipeline off 2>&1 | tail -1
+}
+
+call49() {
+timeout 900 python -m pytest tests/test_gpu_train_data.py tests/test_gpu_drivers.py -x -q > $O/r06_t49.txt 2>&1; echo "tests rc=$?"; tail -4 $O/r06_t49.txt
+for r in 1 2; do
+timeout 600 python tools/solver_rate.py 2>&1 | tail -1
+SOLVER_RATE_HOST_LABELS=1 timeout 600 python tools/solver_rate.py 2>&1 | tail -1
+done
+timeout 600 python tools/solver_rate.py --pipeline off 2>&1 | tail -1
+}
+
+call51() {
+timeout 3000 python -m pytest tests/ -x -q -m gpu > $O/r06_full_suite.txt 2>&1; echo "suite rc=$?"; tail -4 $O/r06_full_suite.txt
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
+}
+
+call52() {
+timeout 900 python -m pytest tests/test_gpu_drivers.py -x -q > $O/r06_t52.txt 2>&1; echo "tests rc=$?"; tail -4 $O/r06_t52.txt
+timeout 600 python tools/feed_rate.py 1 2>&1 | tail -3
+timeout 600 python tools/feed_rate.py 1 plain 2>&1 | tail -3
+timeout 600 python tools/feed_rate.py 2 2>&1 | tail -3
+}
+
+call53() {
+timeout 1500 python -m pytest tests/test_gpu_net.py tests/test_gpu_drivers.py tests/test_gpu_train_data.py tests/test_gpu_configs.py -x -q > $O/r06_t53.txt 2>&1; echo "tests rc=$?"; tail -4 $O/r06_t53.txt
+timeout 600 python tools/feed_rate.py 1 2>&1 | tail -3
+DISYOLO_FEED_LANE=0 timeout 600 python tools/feed_rate.py 1 2>&1 | tail -3
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*'[:80], '|', d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'), d['config'].get('loss_last'))
+"; }
+C="--no-secondary --no-cpu-baseline --no-box --no-kernel-events"
+for r in 1 2; do
+b A=1 timeout 300 python bench.py $C
+b DISYOLO_FEED_LANE=1 timeout 300 python bench.py $C --feed per-step
+b DISYOLO_FEED_LANE=0 timeout 300 python bench.py $C --feed per-step
+timeout 600 python tools/solver_rate.py 2>&1 | tail -1
+DISYOLO_FEED_LANE=0 timeout 600 python tools/solver_rate.py 2>&1 | tail -1
+done
+}
+
+call54() {
+timeout 2400 python -m pytest tests/test_gpu_configs.py tests/test_gpu_dp2.py tests/test_gpu_net.py -x -q > $O/r06_t54.txt 2>&1; echo "tests rc=$?"; grep -n "passed\|failed" $O/r06_t54.txt | tail -2
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*'[:80], '|', d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'), d['config'].get('loss_last'))
+"; }
+C="--no-secondary --no-cpu-baseline --no-box --no-kernel-events"
+for r in 1 2; do
+b A=1 timeout 300 python bench.py $C
+b DISYOLO_DP_TAIL_MAIN=1 timeout 300 python bench.py $C --force-dp
+b DISYOLO_DP_TAIL_MAIN=0 timeout 300 python bench.py $C --force-dp
+done
+}
+
+call55() {
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps2 -- python3 $R/bench.py --stage 2 --steps 10 --repeats 3 --no-cpu-baseline --no-secondary --no-box --no-kernel-events > $O/r06_stage2_under_rocprof.json 2>/dev/null
+cp /tmp/ps2/*/*kernel_stats.csv $O/r06_stage2_kernel_stats.csv
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*'[:80], '|', d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'), d['config'].get('loss_last'))
+"; }
+C="--no-secondary --no-cpu-baseline --no-box --no-kernel-events"
+b DISYOLO_BN_INKERNEL=0 timeout 300 python bench.py $C
+b DISYOLO_BN_INKERNEL=0 timeout 300 python bench.py $C --force-dp
+}
+
 "$@"
