@@ -1,5 +1,5 @@
 """End-to-end example on synthetic data (needs an MI355X): polygon annotations -> GPU data pipeline ->
-Solver (recorded two-lane step, optimizer overlapped with backward) -> TF-format checkpoint -> reload into an
+Solver (recorded pipelined step: the next batch's backbone and its data loading beside the current step) -> TF-format checkpoint -> reload into an
 inference net -> detections + instance masks for one image.
 
     python examples/train_synthetic.py [--steps 40] [--size 192] [--batch 4] [--out /tmp/disyolo_example]
