@@ -26,13 +26,14 @@ ap.add_argument("--steps", type=int, default=300)
 ap.add_argument("--pipeline", default="auto")
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--size", type=int, default=576)
+ap.add_argument("--stage", type=int, default=1)
 ap.add_argument("--json", action="store_true", help="one JSON line instead of the sentence (bench.py's secondary)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 labels = synthetic_labels(np.random.RandomState(0), 64)
 data = defect_train(labels, batch_size=args.batch, image_size=args.size, device=dev, rng=np.random.RandomState(1))
-net = YOLONet(training=True, device=dev, image_size=args.size, batch_size=args.batch, stage=1, seed=0)
-cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "tune_train_B8_576_stage1.json")
+net = YOLONet(training=True, device=dev, image_size=args.size, batch_size=args.batch, stage=args.stage, seed=0)
+cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "tune_train_B8_576_stage%d.json" % args.stage)
 stamps = []
 inner = data.get
 
@@ -75,11 +76,11 @@ n = len(stamps) - skip
 dt = (t_end - stamps[skip]) / n
 if args.json:
     import json
-    print(json.dumps({"workload": "Solver.train over train_data.defect_train (GPU data pipeline), B%d %dx%d, stage 1" % (args.batch, args.size, args.size),
+    print(json.dumps({"workload": "Solver.train over train_data.defect_train (GPU data pipeline), B%d %dx%d, stage %d" % (args.batch, args.size, args.size, args.stage),
                       "value": round(args.batch / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3), "steps": n,
                       "data_pipeline_alone_ms_per_batch": round(t_data * 1e3, 3), "finite_losses": int(np.isfinite(hist).sum()),
                       "records": len(labels)}))
     sys.exit(0)
-print("data pipeline alone %.3f ms per batch; Solver.train: %d steps, %.3f ms per step = %.1f images/s (pipeline %s, feed stream %s); "
-      "finite losses %d of %d" % (t_data * 1e3, n, dt * 1e3, args.batch / dt, args.pipeline, os.environ.get("DISYOLO_FEED_STREAM", "1"),
+print("data pipeline alone %.3f ms per batch; Solver.train (stage %d): %d steps, %.3f ms per step = %.1f images/s (pipeline %s, feed stream %s); "
+      "finite losses %d of %d" % (t_data * 1e3, args.stage, n, dt * 1e3, args.batch / dt, args.pipeline, os.environ.get("DISYOLO_FEED_STREAM", "1"),
                                   int(np.isfinite(hist).sum()), len(hist)))
