@@ -484,4 +484,46 @@ b DISYOLO_BN_INKERNEL=0 timeout 300 python bench.py $C
 b DISYOLO_BN_INKERNEL=0 timeout 300 python bench.py $C --force-dp
 }
 
+call57() {
+timeout 900 python -m pytest tests/test_gpu_conv.py -x -q > $O/r06_t57.txt 2>&1; echo "conv tests rc=$?"; tail -3 $O/r06_t57.txt
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+k = d.get('kernels', {})
+print('$*'[:70], '|', d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'), d['config'].get('loss_last'), {n[:44]: v['avg_us'] for n, v in list(k.items())[:3]})
+"; }
+C="--no-secondary --no-cpu-baseline --no-box"
+for r in 1 2; do
+b A=1 timeout 300 python bench.py $C
+b A=1 timeout 300 python bench.py $C --stage 2 --steps 10 --repeats 5
+b A=1 timeout 300 python bench.py $C --task infer --batch 32 --steps 10 --repeats 5
+done
+}
+
+call58() {
+for shape in "8 18 512 1024 3" "8 18 1024 512 3" "8 36 256 512 3" "8 18 1024 512 1" "8 36 512 256 1" "32 18 512 1024 3" "32 36 256 512 3"; do
+  echo "== $shape  (rotated | straight)"
+  timeout 200 python tools/ab_tile.py $shape 12 0x20c 2>&1 | tail -2
+  DISYOLO_LIB=$R/dis-yolo_amd/libdisyolo_straight.so timeout 200 python tools/ab_tile.py $shape 12 0x20c 2>&1 | tail -2
+done
+}
+
+call59() {
+
+for r in 1 2; do
+timeout 600 python tools/solver_rate.py --stage 2 --steps 150 2>&1 | tail -1
+DISYOLO_SOLVER_AHEAD=0 timeout 600 python tools/solver_rate.py --stage 2 --steps 150 2>&1 | tail -1
+timeout 600 python tools/solver_rate.py --pipeline off 2>&1 | tail -1
+DISYOLO_SOLVER_AHEAD=0 timeout 600 python tools/solver_rate.py --pipeline off 2>&1 | tail -1
+done
+}
+
+call62() {
+timeout 900 python tools/solver_rate.py --steps 4000 2>&1 | tail -2
+timeout 900 python tools/solver_rate.py --steps 1500 --stage 2 2>&1 | tail -2
+timeout 600 python bench.py --steps 300 --repeats 3 --no-secondary --no-cpu-baseline --no-box --no-kernel-events --feed per-step 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench 300-step regions, fed:', d['value'], d['ms_per_step'], d['ms_per_step_min_max'], d['config']['loss_last'], d['config']['steps_trained'])"
+}
+
 "$@"
