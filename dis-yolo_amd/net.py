@@ -641,6 +641,10 @@ class YOLONet(object):
             p = l.idx
         return p
 
+    PIPE_INPUTS = ("images", "clip_window", "labels", "true_boxes", "true_masks", "perm_det", "perm_gt")
+    feed_stream = None
+    _pipe_in = None
+
     def _setup_pipeline(self) -> None:
         P = self._backbone_prefix()
         if P < 2 or not self.training:
@@ -670,9 +674,10 @@ class YOLONet(object):
     def _pick_feed_stream(self) -> None:
         """the stream ``feed_context()`` puts the next batch on.  Single-GPU: lane 3 of the executor's pool (the gradient exchange's
         lane, idle without data parallelism) -- a stream the pool PROBED to run beside the main lane and not to slow it while
-        parked on an event (csrc/runtime.hip pool_lane; profiles/r05_hw_queues.txt).  An arbitrary new stream can be the other
-        kind of neighbour: the host feeder's copies parked its stream on a 2-ms upload and the step beside it took 7.1 ms instead
-        of 3.6 (tools/feed_rate.py).  Data parallel: lane 3 is taken, a plain lowest-priority stream has to do."""
+        parked on an event (csrc/runtime.hip pool_lane; profiles/r05_hw_queues.txt); an arbitrary new stream can be the other
+        kind of neighbour.  (Measured the same as a plain stream for the feeds of this round, tools/feed_rate.py; what did cost a
+        step 7.1 ms instead of 3.6 was a SECOND stream parked on a 2-ms upload's event -- the host feeder now uploads on this
+        stream too.)  Data parallel: lane 3 is taken, a plain lowest-priority stream has to do."""
         if self.device.type != "cuda":
             return
         if self.dp is None and os.environ.get("DISYOLO_FEED_LANE", "1") != "0":
@@ -683,10 +688,6 @@ class YOLONet(object):
         except Exception:
             prio = 0
         self.feed_stream = torch.cuda.Stream(device=self.device, priority=prio)
-
-    PIPE_INPUTS = ("images", "clip_window", "labels", "true_boxes", "true_masks", "perm_det", "perm_gt")
-    feed_stream = None
-    _pipe_in = None
 
     def _use_parity(self, q: int) -> None:
         for i, bufs in self._xbuf.items():
