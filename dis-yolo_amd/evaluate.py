@@ -60,6 +60,7 @@ class MAP(object):
         self.recs_mask, self.sizes, self.index, self.merged = recs_mask, sizes, list(index), merged
         self.net_size = net_size
         self.groundtruth = [recs_mask, merged, sizes, self.index]
+        self._gt_cache = {}
 
     @staticmethod
     def correct_yolo_boxes(x1, y1, x2, y2, image_h, image_w, net_h, net_w):
@@ -84,9 +85,44 @@ class MAP(object):
         per-class lists, return the merged class map (uint8 CUDA [H,W])"""
         image_h, image_w = self.sizes[imageid]
         entries, merged = paste_detections(det_box, det_mask, image_h, image_w, self.net_size)
+        if entries and os.environ.get("DISYOLO_EVAL_GPU_IOU", "1") != "0":
+            # round 6: the mask IoUs voc_eval needs (compute_overlaps_masks: every detection against the image's ground-truth
+            # instances of its class) are taken HERE, on the GPU, from the pasted masks -- pixel counts as exact integers
+            # ([nd, HW] x [HW, ng] in f32: every partial sum is an integer below 2^24), divided on the host in f32 exactly as
+            # numpy does; the 0.5-MB-per-detection copies to the host and the numpy pass over them (145 ms per image) are gone
+            for c in sorted({e["classid"] for e in entries}):
+                dets = [e for e in entries if e["classid"] == c]
+                gt = self._gt_stack(imageid, c, merged.device)
+                if gt is None:
+                    rows = [np.zeros(0, np.float32)] * len(dets)
+                else:
+                    d = torch.stack([e["mask"] for e in dets]).reshape(len(dets), -1).to(torch.float32)
+                    inter = (d @ gt[0]).cpu().numpy()                                    # [nd, ng] f32, exact counts
+                    union = d.sum(1).cpu().numpy()[:, None] + gt[1][None, :] - inter
+                    rows = list((inter / union).astype(np.float32))
+                for e, ov in zip(dets, rows):
+                    detfile[str(c)].append({"imageid": imageid, "score": e["score"], "ov": ov})
+            return merged
         for e in entries:
             detfile[str(e["classid"])].append({"imageid": imageid, "score": e["score"], "mask": e["mask"].cpu().numpy()})
         return merged
+
+    def _gt_stack(self, imageid: str, classid: int, device):
+        """the ground-truth instances of one class of one image, in ``recs_mask`` order (voc_eval's ``objs``): ([HW, ng] f32
+        0 / 1 on the GPU, pixel counts [ng] f32 on the host); None without such instances.  Cached: a validation set is
+        swept many times."""
+        key = (imageid, classid)
+        hit = self._gt_cache.get(key)
+        if hit is None:
+            objs = [o for o in self.recs_mask[imageid] if o["classid"] == classid]
+            if not objs:
+                hit = (None,)
+            else:
+                g = torch.from_numpy(np.stack([np.asarray(o["mask"]).astype(float) > 0.5 for o in objs]).reshape(len(objs), -1))
+                g = g.to(device).to(torch.float32)
+                hit = ((g.t().contiguous(), g.sum(1).cpu().numpy()),)
+            self._gt_cache[key] = hit
+        return hit[0]
 
     def do_python_eval(self, detdata: List[Dict]):
         """utils/validation_map.py:104-198: detdata = [{'boxes' [n,6], 'masks' [n,S,S] (CUDA tensor or numpy)
@@ -116,6 +152,10 @@ def evaluate(net, images: Dict[str, np.ndarray], eval_map: MAP, det_thresh: floa
     if net.B != 1:
         raise ValueError("evaluate() feeds one image at a time (cfg.BATCH_SIZE = 1, calculate_test_map.py:354)")
     S = net.S
+    if (not net.training and getattr(net, "_infer_prog", None) is None and os.environ.get("DISYOLO_EVAL_REPLAY", "1") != "0"):
+        # an inference net: record forward + detection filter + mask assembly once for this threshold (a hipGraph of one lane);
+        # every image is then one replay (YOLONet.evaluation uses the recording when the threshold matches)
+        net.build_infer_program(float(det_thresh), graph=True)
     detfile = {str(c): [] for c in eval_map.classid}
     seg = SegmentationAccuracy(net.device) if eval_map.merged is not None else None
     t_pred = t_crop = 0.0

@@ -1112,12 +1112,19 @@ class YOLONet(object):
         [det_box, det_mask]: per image an [n,6] array and an [n,S/2,S/2] array (scalar 0.0
         when the image has no valid detection, :933).  ``masks_on_device``: det_mask entries stay
         CUDA tensors (10 MB per image at 30 detections -- what postprocess.paste_detections takes)."""
-        self.forward(images, clip_window, det_thresh, is_training=False)
-        Sm = self.S // 2
-        if self.masks is None:
-            self.masks = torch.zeros(self.B, cfg.MAX_DETECTION, Sm, Sm, dtype=F32, device=self.device)
-        L.psroi_assemble(self.by_idx[82].act, self.detections, self.B, cfg.MAX_DETECTION, Sm, self.k, self.masks,
-                         self.keep)
+        thr = float(np.asarray(det_thresh).reshape(-1)[0])
+        if (not self.training and getattr(self, "_infer_prog", None) is not None and getattr(self, "_infer_thresh", None) == thr
+                and not self.pair):
+            # an inference net whose forward + filter + assembly were recorded for this threshold (build_infer_program):
+            # one replay instead of ~90 launches from Python -- the same kernels on the same buffers
+            self.infer(images, clip_window)
+        else:
+            self.forward(images, clip_window, det_thresh, is_training=False)
+            Sm = self.S // 2
+            if self.masks is None:
+                self.masks = torch.zeros(self.B, cfg.MAX_DETECTION, Sm, Sm, dtype=F32, device=self.device)
+            L.psroi_assemble(self.by_idx[82].act, self.detections, self.B, cfg.MAX_DETECTION, Sm, self.k, self.masks,
+                             self.keep)
         keep = self.keep.cpu().numpy().astype(bool)
         det = self.detections.cpu().numpy()
         det_box, det_mask = [], []
@@ -1156,6 +1163,7 @@ class YOLONet(object):
             self.use_side_lane = side_lane
         self.ws.frozen = True
         self._infer_prog = prog
+        self._infer_thresh = float(det_thresh)
         self._infer_graph = None
         if graph:
             side = torch.cuda.Stream(device=self.device)
