@@ -333,6 +333,18 @@ def secondary_measurements(args, dev):
                                                         "with its data loader, as a user runs it")
         except Exception as e:
             out["train_stage1_solver_loop"] = {"error": repr(e)[:200]}
+    # ... and the test loop (evaluate(): one image at a time, paste, mask mAP + mIoU; tools/evaluate_rate.py)
+    if args.stage == 1 and args.dtype == "bf16" and S == 576:
+        try:
+            r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "evaluate_rate.py"),
+                                "32", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+            lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                raise RuntimeError("evaluate_rate exited with %d" % r.returncode)
+            out["evaluate_loop"] = dict(json.loads(lines[-1]), process="child",
+                                        role="not a bench step: the reference's test loop as a user runs it (155 ms per image at the start of round 6)")
+        except Exception as e:
+            out["evaluate_loop"] = {"error": repr(e)[:200]}
     # the headline workload the way a training loop runs it: a new batch before every step (device-to-device set_batch
     # inside the timed region; the overlapped tail stays open across it -- nothing in the tail reads an input tensor)
     if args.stage == 1 and args.dtype == "bf16":

@@ -14,7 +14,9 @@ import disyolo_amd  # noqa: E402,F401
 from disyolo_amd import evaluate as E  # noqa: E402
 from disyolo_amd.net import YOLONet  # noqa: E402
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 48
+as_json = "--json" in sys.argv
+args_ = [a for a in sys.argv[1:] if a != "--json"]
+N = int(args_[0]) if args_ else 48
 S = 576
 dev = torch.device("cuda:0")
 rng = np.random.RandomState(0)
@@ -49,6 +51,13 @@ t0 = time.perf_counter()
 thresh_out, acc, timing = E.evaluate(net, images, emap, det_thresh=0.05)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+if as_json:
+    import json
+    print(json.dumps({"workload": "evaluate() (calculate_test_map.py loop): batch-1 inference at 576x576 + paste + mask mAP / mIoU over %d images of 400-900 px" % N,
+                      "value": round(N / dt, 1), "unit": "images/sec", "ms_per_image": round(dt / N * 1e3, 3),
+                      "prediction_ms_per_image": round(timing["prediction_s"] / N * 1e3, 3),
+                      "crop_assemble_ms_per_image": round(timing["crop_assemble_s"] / N * 1e3, 3)}))
+    sys.exit(0)
 print("evaluate(): %d images of 400-900 px, %.2f ms per image wall (prediction %.2f ms, crop + assemble %.2f ms), replay %s, mAP rows %d"
       % (N, dt / N * 1e3, timing["prediction_s"] / N * 1e3, timing["crop_assemble_s"] / N * 1e3,
          os.environ.get("DISYOLO_EVAL_REPLAY", "1"), len(thresh_out)))
