@@ -526,4 +526,37 @@ import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench 300-step regions, fed:', d['value'], d['ms_per_step'], d['ms_per_step_min_max'], d['config']['loss_last'], d['config']['steps_trained'])"
 }
 
+call63() {
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*'[:90], '|', d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'), d['config'].get('loss_last'))
+"; }
+C="--no-secondary --no-cpu-baseline --no-box --no-kernel-events"
+for r in 1 2; do
+for m in 8 32; do
+b DISYOLO_OPT_CHUNK_M=$m timeout 300 python bench.py $C
+b DISYOLO_OPT_CHUNK_M=$m timeout 300 python bench.py $C --pipeline off
+b DISYOLO_OPT_CHUNK_M=$m timeout 300 python bench.py $C --stage 2 --steps 10 --repeats 5
+b DISYOLO_OPT_CHUNK_M=$m timeout 300 python bench.py $C --force-dp
+done
+done
+}
+
+call64() {
+timeout 900 python -m pytest tests/test_gpu_drivers.py tests/test_gpu_e2e_parity.py -x -q > $O/r06_t64.txt 2>&1; echo "tests rc=$?"; tail -3 $O/r06_t64.txt
+for r in 1 2; do
+timeout 600 python tools/evaluate_rate.py 2>&1 | tail -1
+DISYOLO_EVAL_REPLAY=0 timeout 600 python tools/evaluate_rate.py 2>&1 | tail -1
+done
+}
+
+call66() {
+timeout 900 python -m pytest tests/test_gpu_drivers.py tests/test_voc_eval.py tests/test_postprocess.py -x -q > $O/r06_t66.txt 2>&1; echo "tests rc=$?"; tail -3 $O/r06_t66.txt
+for r in 1 2; do
+timeout 600 python tools/evaluate_rate.py 2>&1 | tail -1
+DISYOLO_EVAL_GPU_IOU=0 timeout 600 python tools/evaluate_rate.py 2>&1 | tail -1
+done
+}
+
 "$@"
