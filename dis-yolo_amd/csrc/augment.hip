@@ -86,46 +86,65 @@ __device__ __forceinline__ bool locate(int y, int x, int S, int new_w, int new_h
 
 // uint8 image: OpenCV's 8-bit bilinear path works in fixed point -- coefficients rounded to 11 bits,
 // horizontal pass in int, vertical pass (b0*S0 + b1*S1 + 2^21) >> 22
+__device__ __forceinline__ void place_image_px(const unsigned char* src, int H, int W, unsigned char* dst, int S, int new_w, int new_h,
+                                               int dx, int dy, int flip, int64_t i) {
+  const int y = (int)(i / S), x = (int)(i - (int64_t)y * S);
+  int ry, rx;
+  unsigned char v[3] = {127, 127, 127};
+  if (locate(y, x, S, new_w, new_h, dx, dy, flip, &ry, &rx)) {
+    const Taps tx = taps(rx, new_w, W), ty = taps(ry, new_h, H);
+    const int ax1 = (int)rintf(tx.a * 2048.f), ax0 = 2048 - ax1;
+    const int ay1 = (int)rintf(ty.a * 2048.f), ay0 = 2048 - ay1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int h0 = src[((size_t)ty.s0 * W + tx.s0) * 3 + c] * ax0 + src[((size_t)ty.s0 * W + tx.s1) * 3 + c] * ax1;
+      const int h1 = src[((size_t)ty.s1 * W + tx.s0) * 3 + c] * ax0 + src[((size_t)ty.s1 * W + tx.s1) * 3 + c] * ax1;
+      const int r = (h0 * ay0 + h1 * ay1 + (1 << 21)) >> 22;
+      v[c] = (unsigned char)min(max(r, 0), 255);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) dst[i * 3 + c] = v[c];
+}
 __global__ __launch_bounds__(256) void place_image_kernel(const unsigned char* src, int H, int W, unsigned char* dst, int S,
                                                           int new_w, int new_h, int dx, int dy, int flip) {
   const int64_t total = (int64_t)S * S;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int y = (int)(i / S), x = (int)(i - (int64_t)y * S);
-    int ry, rx;
-    unsigned char v[3] = {127, 127, 127};
-    if (locate(y, x, S, new_w, new_h, dx, dy, flip, &ry, &rx)) {
-      const Taps tx = taps(rx, new_w, W), ty = taps(ry, new_h, H);
-      const int ax1 = (int)rintf(tx.a * 2048.f), ax0 = 2048 - ax1;
-      const int ay1 = (int)rintf(ty.a * 2048.f), ay0 = 2048 - ay1;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int h0 = src[((size_t)ty.s0 * W + tx.s0) * 3 + c] * ax0 + src[((size_t)ty.s0 * W + tx.s1) * 3 + c] * ax1;
-        const int h1 = src[((size_t)ty.s1 * W + tx.s0) * 3 + c] * ax0 + src[((size_t)ty.s1 * W + tx.s1) * 3 + c] * ax1;
-        const int r = (h0 * ay0 + h1 * ay1 + (1 << 21)) >> 22;
-        v[c] = (unsigned char)min(max(r, 0), 255);
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) dst[i * 3 + c] = v[c];
-  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    place_image_px(src, H, W, dst, S, new_w, new_h, dx, dy, flip, i);
 }
 
 // float mask (0/1 bytes in, treated as float32): float bilinear path, pad 0, np.around (half to even) -> bool
+__device__ __forceinline__ void place_mask_px(const unsigned char* src, int H, int W, unsigned char* dst, int S, int new_w, int new_h,
+                                              int dx, int dy, int flip, int64_t i) {
+  const int y = (int)(i / S), x = (int)(i - (int64_t)y * S);
+  int ry, rx;
+  float v = 0.f;
+  if (locate(y, x, S, new_w, new_h, dx, dy, flip, &ry, &rx)) {
+    const Taps tx = taps(rx, new_w, W), ty = taps(ry, new_h, H);
+    const float bx = __fsub_rn(1.f, tx.a), by = __fsub_rn(1.f, ty.a);
+    const float h0 = __fadd_rn(__fmul_rn((float)src[(size_t)ty.s0 * W + tx.s0], bx), __fmul_rn((float)src[(size_t)ty.s0 * W + tx.s1], tx.a));
+    const float h1 = __fadd_rn(__fmul_rn((float)src[(size_t)ty.s1 * W + tx.s0], bx), __fmul_rn((float)src[(size_t)ty.s1 * W + tx.s1], tx.a));
+    v = __fadd_rn(__fmul_rn(h0, by), __fmul_rn(h1, ty.a));
+  }
+  dst[i] = rintf(v) != 0.f ? 1 : 0;
+}
 __global__ __launch_bounds__(256) void place_mask_kernel(const unsigned char* src, int H, int W, unsigned char* dst, int S,
                                                          int new_w, int new_h, int dx, int dy, int flip) {
   const int64_t total = (int64_t)S * S;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    place_mask_px(src, H, W, dst, S, new_w, new_h, dx, dy, flip, i);
+}
+
+// a whole batch's placements in ONE launch (round 6: the loader's ~25 per-image / per-instance launches were its GPU time):
+// blockIdx.y = job; the per-pixel arithmetic is the single-job kernels' own
+__global__ __launch_bounds__(256) void place_batch_kernel(const disyolo_place_job* jobs, int S) {
+  const disyolo_place_job j = jobs[blockIdx.y];
+  const int64_t total = (int64_t)S * S;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int y = (int)(i / S), x = (int)(i - (int64_t)y * S);
-    int ry, rx;
-    float v = 0.f;
-    if (locate(y, x, S, new_w, new_h, dx, dy, flip, &ry, &rx)) {
-      const Taps tx = taps(rx, new_w, W), ty = taps(ry, new_h, H);
-      const float bx = __fsub_rn(1.f, tx.a), by = __fsub_rn(1.f, ty.a);
-      const float h0 = __fadd_rn(__fmul_rn((float)src[(size_t)ty.s0 * W + tx.s0], bx), __fmul_rn((float)src[(size_t)ty.s0 * W + tx.s1], tx.a));
-      const float h1 = __fadd_rn(__fmul_rn((float)src[(size_t)ty.s1 * W + tx.s0], bx), __fmul_rn((float)src[(size_t)ty.s1 * W + tx.s1], tx.a));
-      v = __fadd_rn(__fmul_rn(h0, by), __fmul_rn(h1, ty.a));
-    }
-    dst[i] = rintf(v) != 0.f ? 1 : 0;
+    if (j.is_mask)
+      place_mask_px(j.src, j.image_h, j.image_w, j.dst, S, j.new_w, j.new_h, j.dx, j.dy, j.flip, i);
+    else
+      place_image_px(j.src, j.image_h, j.image_w, j.dst, S, j.new_w, j.new_h, j.dx, j.dy, j.flip, i);
   }
 }
 
@@ -239,6 +258,16 @@ extern "C" int disyolo_aug_place(const uint8_t* src, int is_mask, int image_h, i
     hipLaunchKernelGGL(place_mask_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, src, image_h, image_w, dst, size, new_w, new_h, dx, dy, flip);
   else
     hipLaunchKernelGGL(place_image_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, src, image_h, image_w, dst, size, new_w, new_h, dx, dy, flip);
+  DY_CHECK_LAUNCH();
+  return DISYOLO_OK;
+}
+
+extern "C" int disyolo_aug_place_batch(const disyolo_place_job* jobs, int njobs, int size, void* stream) {
+  DY_REQUIRE(jobs && njobs > 0 && njobs <= 65535 && size > 0, "aug_place_batch: bad args");
+  DY_RECORD_OR_RUN([=](void* s) { return disyolo_aug_place_batch(jobs, njobs, size, s); });
+  int gx = grid_for((int64_t)size * size);
+  if (gx > 512) gx = 512;     // (grid-stride: the jobs of a batch fill the chip between them)
+  hipLaunchKernelGGL(place_batch_kernel, dim3(gx, njobs), dim3(256), 0, (hipStream_t)stream, jobs, size);
   DY_CHECK_LAUNCH();
   return DISYOLO_OK;
 }

@@ -10,6 +10,7 @@ import ctypes as C
 import os
 from typing import Optional
 
+import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -173,6 +174,7 @@ _SIGS = {
     "disyolo_cast_bf16_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "disyolo_polygon_mask": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p]),
     "disyolo_aug_place": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
+    "disyolo_aug_place_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "disyolo_aug_salt_pepper": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "disyolo_aug_change_light": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
     "disyolo_aug_motion_blur3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -916,6 +918,19 @@ def aug_place(src, is_mask: bool, dst, size: int, new_w: int, new_h: int, dx: in
     _need(dst, torch.uint8, "dst")
     _check(load().disyolo_aug_place(_p(src), int(is_mask), int(src.shape[0]), int(src.shape[1]), _p(dst), size, new_w, new_h,
                                     dx, dy, flip, _stream()), "aug_place")
+
+
+PLACE_JOB = np.dtype([("src", np.uint64), ("dst", np.uint64), ("is_mask", np.int32), ("image_h", np.int32), ("image_w", np.int32),
+                      ("new_w", np.int32), ("new_h", np.int32), ("dx", np.int32), ("dy", np.int32), ("flip", np.int32)])
+assert PLACE_JOB.itemsize == 48      # (disyolo_place_job, include/disyolo.h)
+
+
+def aug_place_batch(jobs_dev, njobs: int, size: int) -> None:
+    """jobs_dev: uint8 CUDA tensor holding njobs PLACE_JOB records (uploaded by the caller on this stream)"""
+    _need(jobs_dev, torch.uint8, "jobs")
+    if jobs_dev.numel() < njobs * PLACE_JOB.itemsize:
+        raise DisyoloError("aug_place_batch: %d jobs do not fit %d bytes" % (njobs, jobs_dev.numel()))
+    _check(load().disyolo_aug_place_batch(_p(jobs_dev), njobs, size, _stream()), "aug_place_batch")
 
 
 def aug_salt_pepper(image, size: int, rows, cols, nsalt: int, npepper: int) -> None:

@@ -18,8 +18,9 @@ Round 6: what does not depend on the random draws is computed ONCE per record an
 rasterised instance masks, their boxes (``load_mask`` / ``load_box`` of the reference run again on every visit of an image and return
 the same arrays every time).  A 1000 x 1000 image with three instances is 6 MB; ``cache_bytes`` (default 16 GiB of the 288) bounds
 it, records beyond the budget are recomputed per visit as before.  With it ``get()`` has no host synchronisation left; with the
-target grids kept sparse on the host (a dozen rows in 5 MB of zeros) and uploaded from pinned staging: 7.5 -> 1.5 ms per batch of 8 at 576^2, and ``Solver.train`` end to end 630 -> 2120 images/s
-(``tools/solver_rate.py``: the step's own rate).
+target grids kept sparse on the host (a dozen rows in 5 MB of zeros) and uploaded from pinned staging, and all placements of a batch (images and instance masks) in one launch: 7.5 -> 1.4 ms per batch of 8
+at 576^2; ``Solver.train`` end to end 630 -> 2100 images/s in stage 1 (the step's own rate), 806 in stage 2 (the step: 833)
+(``tools/solver_rate.py``).
 """
 from __future__ import annotations
 
@@ -104,7 +105,14 @@ class defect_train(object):
         for st in self._host:
             st[4][:, 2:] = 1.0                                 # window = (0, 0, 1, 1), :46-47
         self._last = None
-        self._frame = [torch.zeros(S, S, 3, dtype=torch.uint8, device=dev) for _ in range(2)]
+        # uint8 frames of the batch (the placed images, augmented in place) + one scratch frame for the motion blur; the
+        # placement jobs of a batch (images and instance masks: ONE launch, csrc/augment.hip place_batch_kernel) are written
+        # into pinned staging and uploaded with the batch's other small arrays
+        self._frames = torch.zeros(B, S, S, 3, dtype=torch.uint8, device=dev)
+        self._blur = torch.zeros(S, S, 3, dtype=torch.uint8, device=dev)
+        njob = B * (1 + G)
+        self._jobs_host = [torch.zeros(njob * L.PLACE_JOB.itemsize, dtype=torch.uint8, pin_memory=dev.type == "cuda") for _ in range(2)]
+        self._jobs_dev = [torch.zeros(njob * L.PLACE_JOB.itemsize, dtype=torch.uint8, device=dev) for _ in range(2)]
         self.last_decisions: List[Dict] = []                   # the random draws of the last get(), for tests / logging
         # per-record static part (image on the GPU, instance masks, boxes, classes), keyed by the record object
         self.cache_bytes = int(cache_bytes)
@@ -172,6 +180,10 @@ class defect_train(object):
         written = self._written[turn] = []
         self.true_masks.zero_()
         self.last_decisions = []
+        jobs = self._jobs_host[turn].numpy().view(L.PLACE_JOB)
+        njobs = 0
+        photo = []          # (image index, what, arguments): the photometric step of the images that drew one
+        alive = []          # sources of records beyond the cache budget: held until the launch that reads them is enqueued
         for count in range(B):
             label = self.random_labels[self.cursor]
             image_h, image_w, src, masks, boxes, cls = self._record(label)
@@ -239,33 +251,33 @@ class defect_train(object):
             if self.blur_noise_light:
                 bnl = int(rng.randint(low=1, high=5))
             dec = {"scale_crop": scale_crop, "new_w": new_w, "new_h": new_h, "dx": dx, "dy": dy, "flip": flip, "bnl": bnl}
-            # ---- pixels (image_read :376-416, resize_mask :418-444) on the GPU
-            f0, f1 = self._frame
-            L.aug_place(src, False, f0, S, new_w, new_h, dx, dy, flip)
+            # ---- pixels (image_read :376-416, resize_mask :418-444) on the GPU: the placements as jobs of the batch's one
+            #      launch, the photometric step noted for after it (the draws happen here, in the reference's order)
+            alive.append((src, masks))
+            jobs[njobs] = (src.data_ptr(), self._frames[count].data_ptr(), 0, image_h, image_w, new_w, new_h, dx, dy, flip)
+            njobs += 1
+            for j, m in enumerate(masks):
+                jobs[njobs] = (m.data_ptr(), self.true_masks[count, j].data_ptr(), 1, image_h, image_w, new_w, new_h, dx, dy, flip)
+                njobs += 1
             if bnl == 2:                                                                    # salt & pepper (:511-525)
                 n_el = S * S * 3
                 ns, npp = int(math.ceil(0.004 * n_el * 0.2)), int(math.ceil(0.004 * n_el * 0.8))
                 cs = [rng.randint(0, i - 1, ns) for i in (S, S, 3)]
                 cp = [rng.randint(0, i - 1, npp) for i in (S, S, 3)]
-                rows = torch.from_numpy(np.concatenate([cs[0], cp[0]]).astype(np.int32)).to(dev)
-                cols = torch.from_numpy(np.concatenate([cs[1], cp[1]]).astype(np.int32)).to(dev)
-                L.aug_salt_pepper(f0, S, rows, cols, ns, npp)
+                photo.append((count, "salt_pepper", (np.concatenate([cs[0], cp[0]]).astype(np.int32),
+                                                     np.concatenate([cs[1], cp[1]]).astype(np.int32), ns, npp)))
                 dec.update(salt=(cs[0], cs[1]), pepper=(cp[0], cp[1]))
             elif bnl == 3:                                                                  # light (:527-535)
                 coeff = rng.uniform() + 0.5
-                L.aug_change_light(f0, S, coeff)
+                photo.append((count, "light", (coeff,)))
                 dec["coeff"] = coeff
             elif bnl == 4:                                                                  # motion blur (:466-494)
                 length_idx = rng.randint(0, 1)                                              # lineLengths = [3]
                 type_idx = int(rng.randint(0, 3))                                           # right, left, full
                 angles = np.linspace(0, 180, 4, endpoint=False)                             # kernel centre 1 -> 4 lines
                 angle = int(angles[rng.randint(0, len(angles))])
-                L.aug_motion_blur3(f0, f1, S, angle, {0: 1, 1: 2, 2: 0}[type_idx])
-                f0 = f1
+                photo.append((count, "blur", (angle, {0: 1, 1: 2, 2: 0}[type_idx])))
                 dec.update(angle=angle, line_type=("right", "left", "full")[type_idx], _len=int(length_idx))
-            L.aug_to_float(f0, self.images[count])
-            for j, m in enumerate(masks):
-                L.aug_place(m, True, self.true_masks[count, j], S, new_w, new_h, dx, dy, flip)
             # ---- normalise (:250-257)
             true_boxes[count, 0, 0, 0, :len(bx), :4] = bx / S
             true_boxes[count, 0, 0, 0, :len(bx), 4] = cls
@@ -281,6 +293,21 @@ class defect_train(object):
                 self.random_labels = copy.copy(self.gt_labels)
                 self.cursor = 0
                 self.epoch += 1
+        # ---- the batch's pixel work: one placement launch, the photometric steps, one /255
+        jd = self._jobs_dev[turn]
+        jd[:njobs * L.PLACE_JOB.itemsize].copy_(self._jobs_host[turn][:njobs * L.PLACE_JOB.itemsize], non_blocking=True)
+        L.aug_place_batch(jd, njobs, S)
+        for count, what, a in photo:
+            f = self._frames[count]
+            if what == "salt_pepper":
+                L.aug_salt_pepper(f, S, torch.from_numpy(a[0]).to(dev), torch.from_numpy(a[1]).to(dev), a[2], a[3])
+            elif what == "light":
+                L.aug_change_light(f, S, a[0])
+            else:
+                L.aug_motion_blur3(f, self._blur, S, a[0], a[1])
+                f.copy_(self._blur)
+        L.aug_to_float(self._frames, self.images)
+        del alive
         if dev.type == "cuda":
             for h, d in zip(host, self._dev[turn]):
                 d.copy_(h, non_blocking=True)

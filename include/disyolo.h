@@ -501,6 +501,15 @@ int disyolo_polygon_mask(const float* px, const float* py, const int32_t* poly_s
  * [size,size,3]; is_mask = 1: src uint8 0/1 [H,W] resized as float32, pad 0, np.around, dst uint8 0/1. */
 int disyolo_aug_place(const uint8_t* src, int is_mask, int image_h, int image_w, uint8_t* dst, int size,
                       int new_w, int new_h, int dx, int dy, int flip, void* stream);
+/* a whole batch's placements in one launch (round 6).  jobs: DEVICE array of njobs entries; per-pixel arithmetic = disyolo_aug_place's
+ * (image: OpenCV's 8-bit fixed-point bilinear path, pad 127; mask: float bilinear, pad 0, half-to-even rounding to 0 / 1).
+ * Replaces nothing in the reference (its loader is host code, utils/train_data.py:376-444); it replaces ~25 launches per batch here. */
+typedef struct disyolo_place_job {
+  const uint8_t* src;      /* image [image_h, image_w, 3] or mask [image_h, image_w], uint8 */
+  uint8_t* dst;            /* [size, size, 3] or [size, size] */
+  int32_t is_mask, image_h, image_w, new_w, new_h, dx, dy, flip;
+} disyolo_place_job;
+int disyolo_aug_place_batch(const disyolo_place_job* jobs, int njobs, int size, void* stream);
 /* add_salt_pepper_noise (:511-525): pixels (rows[i], cols[i]) <- 1 for i < nsalt, then <- 0 for the next npepper */
 int disyolo_aug_salt_pepper(uint8_t* image, int size, const int32_t* rows, const int32_t* cols, int nsalt,
                             int npepper, void* stream);
