@@ -559,4 +559,34 @@ DISYOLO_EVAL_GPU_IOU=0 timeout 600 python tools/evaluate_rate.py 2>&1 | tail -1
 done
 }
 
+call69() {
+b() { env "$@" 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*'[:100], '|', d['value'], d['ms_per_step'], d.get('ms_per_step_min_max'))
+"; }
+C="--no-secondary --no-cpu-baseline --no-box --no-kernel-events --stage 2 --steps 10 --repeats 5"
+for r in 1 2; do
+b A=1 timeout 300 python bench.py $C
+b A=1 timeout 300 python bench.py $C --feed per-step
+b A=1 timeout 300 python bench.py $C --overlap-tail off
+done
+timeout 300 python tools/host_enqueue.py 2 2>&1 | tail -3
+}
+
+call70() {
+for r in 1 2; do
+DISYOLO_SOLVER_AHEAD=1 timeout 600 python tools/solver_rate.py --stage 2 --steps 150 2>&1 | tail -1
+DISYOLO_SOLVER_AHEAD=0 timeout 600 python tools/solver_rate.py --stage 2 --steps 150 2>&1 | tail -1
+done
+}
+
+call71() {
+timeout 900 python -m pytest tests/test_gpu_train_data.py tests/test_gpu_drivers.py -x -q > $O/r06_t71.txt 2>&1; echo "tests rc=$?"; tail -5 $O/r06_t71.txt
+for r in 1 2; do
+timeout 600 python tools/solver_rate.py 2>&1 | tail -1
+timeout 600 python tools/solver_rate.py --stage 2 --steps 150 2>&1 | tail -1
+done
+}
+
 "$@"
