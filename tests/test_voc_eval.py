@@ -47,3 +47,30 @@ def test_known_answer_three_detections_two_gt():
     r, p, ap = voc_eval(dets, recs, ["a"], 0)
     assert abs(r - 1.0) < 1e-12 and abs(p - 2.0 / 3.0) < 1e-12 and abs(ap - 5.0 / 6.0) < 1e-12
     assert voc_eval([], recs, ["a"], 0) == (0.0, 0.0, 0.0)
+
+
+def test_voc_eval_with_precomputed_overlap_rows_equals_the_mask_path():
+    """round 6: evaluate.MAP.collect hands voc_eval the IoU row of every detection (taken on the GPU from exact pixel counts)
+    instead of its mask.  Same golden cases: rows computed the way collect computes them (counts, f32 division) give the reference's
+    recall / precision / AP, and equal the mask path's bit for bit."""
+    for case in G["cases"]:
+        recs = {n: [{"classid": o["classid"], "difficult": o["difficult"], "mask": np.asarray(o["mask"], np.uint8)}
+                    for o in objs] for n, objs in case["recs"].items()}
+        for c in sorted({d["classid"] for d in case["dets"]}):
+            dets = [{"imageid": d["imageid"], "score": d["score"], "mask": np.asarray(d["mask"], np.uint8)}
+                    for d in case["dets"] if d["classid"] == c]
+            rows = []
+            for d in dets:
+                objs = [o for o in recs[d["imageid"]] if o["classid"] == c]
+                if not objs:
+                    rows.append({"imageid": d["imageid"], "score": d["score"], "ov": np.zeros(0, np.float32)})
+                    continue
+                g = np.stack([(o["mask"].astype(float) > 0.5).reshape(-1) for o in objs]).astype(np.float32)     # [ng, HW]
+                m = (d["mask"].astype(float) > 0.5).reshape(-1).astype(np.float32)
+                inter = g @ m
+                union = m.sum() + g.sum(1) - inter
+                rows.append({"imageid": d["imageid"], "score": d["score"], "ov": (inter / union).astype(np.float32)})
+            names = case["names"]
+            want = voc_eval(dets, recs, names, c, ovthresh=0.5)
+            got = voc_eval(rows, recs, names, c, ovthresh=0.5)
+            np.testing.assert_array_equal(np.asarray(got, float), np.asarray(want, float))     # (NaN where there is no ground truth: in both)
