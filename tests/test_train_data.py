@@ -75,3 +75,54 @@ def test_motion_blur_restatement_equals_scipy_convolve2d():
     out = O.motion_blur3(one, 90, 1).astype(int)[:, :, 0]
     assert out[2, 2] == 45 and out[3, 2] == 45 and out[1, 2] == 0        # the impulse spreads DOWN
     assert out[0, 0] == 127                                              # border: (0 + 255) / 2
+
+
+def test_sparse_target_rows_flipped_and_normalised_equal_the_dense_grids():
+    """round 6: the loader keeps the three target grids as their non-zero rows (synth.assign_target_entries) and applies the flip
+    (utils/train_data.py:187-226) and the /net_size (:250-257) to the rows.  Against the dense form of those lines -- mirrored grid
+    copies, centres reflected where the object flag is set, the whole grid divided -- on random boxes, all three flips: equal."""
+    from disyolo_amd.synth import assign_target_entries, assign_targets
+    S, C = 192, 3
+    rng = np.random.RandomState(4)
+    for trial in range(40):
+        n = int(rng.randint(0, 7))
+        wh = rng.uniform(6, 150, (n, 2))
+        ctr = np.stack([rng.uniform(wh[:, 0] / 2, S - 1 - wh[:, 0] / 2), rng.uniform(wh[:, 1] / 2, S - 1 - wh[:, 1] / 2)], 1)
+        bx = np.concatenate([ctr, wh], 1).astype(np.float32)
+        cls = [int(v) for v in rng.randint(0, C, n)]
+        flip = 1 + trial % 3
+        # dense (the reference's form)
+        grids = assign_targets(bx, cls, S, C)
+        if flip == 2:
+            grids = [g[:, ::-1].copy() for g in grids]
+            for g in grids:
+                obj = g[..., 4] == 1
+                g[..., 0][obj] = S - 1 - g[..., 0][obj]
+        elif flip == 3:
+            grids = [g[::-1].copy() for g in grids]
+            for g in grids:
+                obj = g[..., 4] == 1
+                g[..., 1][obj] = S - 1 - g[..., 1][obj]
+        want = []
+        for g in grids:
+            g = g.copy()
+            g[..., 0:4] = g[..., 0:4] / S
+            want.append(g)
+        # sparse (train_data.defect_train._fill)
+        ents = assign_target_entries(bx, cls, S, C)
+        got = [np.zeros_like(w) for w in want]
+        for k, ent in enumerate(ents):
+            gsz = got[k].shape[1]
+            if flip == 2:
+                for row in ent.values():
+                    row[0] = np.float32(S - 1) - row[0]
+                ent = {(yi, gsz - 1 - xi, a): row for (yi, xi, a), row in ent.items()}
+            elif flip == 3:
+                for row in ent.values():
+                    row[1] = np.float32(S - 1) - row[1]
+                ent = {(gsz - 1 - yi, xi, a): row for (yi, xi, a), row in ent.items()}
+            for (yi, xi, a), row in ent.items():
+                row[0:4] = row[0:4] / np.float32(S)
+                got[k][yi, xi, a] = row
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w), (trial, flip)
